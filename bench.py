@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py — encode throughput of BRIEF's SIREN fit loop on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json metric: "voxels/sec encode (512^3 vol, 4x256 SIREN)"):
+  N=1  SingleTask: synthetic 512^3 uint16 volume, SIREN layers=5 features=256 ("4x256") w0=20,
+       randompoint sampler sample_size=100000 (main.py:324-334: volumes > 80^3 use randompoint),
+       datal2 loss, Adamax lr 1e-3 + MultiStepLR — the shipped default.yaml settings.
+  N>1  DivideTask: every rank fits its own 512^3 block of a (N x 512^3) volume with its own 4x256
+       net (independent units, main.py:547-575) — weak scaling, no collective on the data path;
+       RCCL only for the barrier/max-time and the final SSE (PSNR) all-reduce.
+A step = one pass of the hot path over one batch: sample 100000 voxels -> fused forward/loss/
+backward -> optimizer update.  value = sampled voxels fitted per second over all ranks, with
+the volume resident in HBM when the timed region starts.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from brief_pytorch_amd import _lib  # noqa: E402
+from brief_pytorch_amd.fit import Fitter  # noqa: E402
+from brief_pytorch_amd.networks import SIREN  # noqa: E402
+from brief_pytorch_amd.synthetic import make_volume_torch  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz x 256 FLOP/clk
+LAYERS, FEATURES, W0, SAMPLE = 5, 256, 20.0, 100000
+BLOCK = (512, 512, 512)
+
+
+def flops_per_sample(L, F, cin=3, cout=1):
+    M = cin * F + (L - 2) * F * F + F * cout
+    train = 2 * (3 * M - cin * F)
+    fused = 2 * M + 2 * ((L - 2) * F * F + F * cout) + 2 * (cin * F + F * cout)     # fwd + dgrad + skinny wgrads
+    return train, fused, 2 * M
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """The oracle (a port of the reference algorithm, OpenMP over samples) timed on this host on
+    the same step: 100000 samples, 4x256 SIREN, fwd+loss+bwd+Adamax."""
+    from oracle import oracle as O
+    d = O.make_desc(3, 1, LAYERS, FEATURES, W0)
+    rng = np.random.default_rng(0)
+    torch.manual_seed(0)
+    p = SIREN(features=FEATURES, layers=LAYERS, w0=W0).params.numpy().copy()
+    n = SAMPLE
+    x = rng.uniform(-1, 1, size=(n, 3)).astype(np.float32)
+    y = rng.uniform(0, 100, size=(n, 1)).astype(np.float32)
+    s1, s2 = np.zeros_like(p), np.zeros_like(p)
+    t0 = time.perf_counter()
+    steps = 0
+    while True:
+        loss, g, _, _ = O.loss_grad(d, p, x, y)
+        O.optim_step("Adamax", p, g, s1, s2, 1e-3, steps + 1)
+        steps += 1
+        el = time.perf_counter() - t0
+        if el > seconds_budget or steps >= 8:
+            break
+    return {"value": n * steps / el, "unit": "voxels/s", "cores": O.lib().oracle_num_threads(), "kind": "port",
+            "sample": "%d step(s) of %d samples, 4x256 SIREN fwd+loss+bwd+Adamax, oracle/siren_oracle.c (OpenMP)" % (steps, n)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-psnr", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    _lib.lib()   # fails loudly when the HIP extension is missing
+
+    # ---- data: this rank's block, generated and normalised on the device (utils/io.py:65-80 op order)
+    vol = make_volume_torch(BLOCK, seed=42 + rank, device=dev)
+    tgt = vol.view(-1, 1).to(torch.float32)     # (torch has no uint16 min/max kernels)
+    vmin, vmax = float(tgt.min().item()), float(tgt.max().item())
+    tgt = (tgt - np.float32(vmin)) / np.float32(vmax - vmin)
+    tgt *= np.float32(100.0)
+    tgt += np.float32(0.0)
+    torch.manual_seed(42)
+    net = SIREN(coords_channel=3, data_channel=1, features=FEATURES, layers=LAYERS, w0=W0).to(dev)
+    fit = Fitter(net, tgt, BLOCK, sampler="randompoint", sample_size=SAMPLE, optimizer="Adamax", lr=1e-3,
+                 scheduler={"name": "MultiStepLR", "milestones": [50000, 60000, 70000], "gamma": 0.2}, seed=42 + rank)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        fit.step()
+    L = _lib.lib()
+    barrier()
+    _lib.check(L.brief_profile_enable(1))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = fit.step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tot_ms, launches = C.c_double(0), C.c_int64(0)
+    _lib.check(L.brief_profile_fused(C.byref(tot_ms), C.byref(launches)))
+    _lib.check(L.brief_profile_enable(0))
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- PSNR of the (briefly trained) net: decode the block, SSE all-reduce over ranks
+    psnr = None
+    if not args.no_psnr:
+        dec = net.decode_grid(BLOCK, out_kind="u16", scale=(0.0, 100.0), vrange=(vmin, vmax))
+        sse = torch.zeros(1, dtype=torch.float64, device=dev)
+        _lib.check(L.brief_sse_u16(_lib.ptr(vol), _lib.ptr(dec), vol.numel(), _lib.ptr(sse), _lib.stream_ptr()))
+        cnt = torch.tensor([float(vol.numel())], dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(sse)
+            dist.all_reduce(cnt)
+        psnr = float(-10.0 * np.log10(sse.item() / cnt.item() / 65535.0 ** 2))
+
+    if rank == 0:
+        train_f, fused_f, _ = flops_per_sample(LAYERS, FEATURES)
+        fused_ms = tot_ms.value / max(launches.value, 1)
+        achieved = fused_f * SAMPLE / (fused_ms * 1e-3) / 1e12
+        ms_step = elapsed * 1e3 / args.steps
+        value = SAMPLE * args.steps * world / elapsed
+        out = {
+            "metric": "encode_voxels_per_sec", "value": value, "unit": "voxels/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "SingleTask 512^3 synthetic uint16 volume%s, SIREN 4x256 (layers=5, features=256, w0=20), "
+                                   "randompoint sample_size=100000, datal2, Adamax lr=1e-3" %
+                                   ("" if world == 1 else " per rank (DivideTask: %d independent 512^3 blocks)" % world),
+                       "volume": list(BLOCK), "layers": LAYERS, "features": FEATURES, "sample_size": SAMPLE,
+                       "params": net.param_count, "bits_per_voxel": 32.0 * net.param_count / float(np.prod(BLOCK))},
+            "roofline": {"bound": "mfma", "kernel": "k_fused<8,true> (forward+loss+dgrad)", "achieved": achieved,
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                         "traffic": None, "kernel_ms": fused_ms, "flop_per_launch": fused_f * SAMPLE,
+                         "step_tflops": train_f * SAMPLE / (ms_step * 1e-3) / 1e12,
+                         "step_frac": train_f * SAMPLE / (ms_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS},
+            "loss": float(loss.item()), "psnr_db": psnr, "psnr_after_steps": args.steps + args.warmup,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,1091 @@
+// brief_hip.hip — gfx950 (MI355X, CDNA4) kernels + C-ABI for BRIEF's SIREN fit/decode path.
+//
+// Reference path replaced (citations into RichealYoung/BRIEF_PyTorch):
+//   SIREN.forward            utils/Networks.py:269-271, Sine :227-234
+//   loss + autograd backward main.py:176-191, 391-396
+//   optimizer step           utils/misc.py:174-183 (torch.optim.Adamax/Adam/SGD), main.py:399
+//   samplers / coords        main.py:126-163, utils/dataset.py:11-62
+//   decode + de-normalise    main.py:266-297, utils/misc.py:59-92, utils/io.py:136-147
+//
+// Design (DESIGN.md has the full story).  Everything is computed in the TRANSPOSED form
+//   Z^T[feature][sample] = W[feature][k] * H^T[k][sample]
+// with v_mfma_f32_32x32x2_f32 (exact f32, 64 cycles/SIMD).  In that form the C/D accumulator
+// layout (lane&31 = sample, register = feature row) is exactly the B-operand layout of the next
+// layer's MFMA, so activations move between layers as a plain "register image" (no transposes):
+// each wave writes its 32-feature tiles to LDS and every wave of the workgroup reads the whole
+// image back as B operands.  The weights are the A operand; brief_siren_repack stores them in
+// fragment order so each wave-instruction loads one contiguous 1 KiB block (L2 resident).
+//
+//   k_fused<NT,TRAIN>  coords -> layer0 -> hidden layers -> head -> loss -> dgrad chain.
+//                      TRAIN stores Z_l (pre-activations) and D_l (deltas) as [feature][sample]
+//                      panels for the weight-gradient GEMM and accumulates the skinny gradients
+//                      (first layer, head) itself.
+//   k_wgrad<NT>        dW_l = D_l * sin(w Z_{l-1})^T, split-K over sample chunks, fp32 slabs.
+//   k_reduce           deterministic slab/record reduction -> canonical gradient buffer + loss.
+//   k_optim            Adamax / Adam / SGD elementwise update (bit-matches the oracle's rule).
+//   k_repack           canonical params -> fragment-ordered copies.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "brief_layout.h"
+#include "brief_math.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// row of accumulator register r (0..15) inside a 32x32 tile, for lane half hi
+#define ROWMAP(r, hi) (((r) & 3) + 8 * ((r) >> 2) + 4 * (hi))
+
+template <int NT>
+struct KCfg {
+    static constexpr int WM = NT >= 3 ? 4 : NT;       // waves along the feature dimension
+    static constexpr int WS = 4 / WM;                 // 32-sample tiles per workgroup
+    static constexpr int MTW = (NT + WM - 1) / WM;    // feature tiles owned by one wave
+    static constexpr bool EXACT = (NT % WM) == 0;
+    static constexpr int FP = 32 * NT;
+    static constexpr int XS_FLOATS = WS * NT * 1024;  // activation image(s)
+    static constexpr int T_FLOATS = 4 * 64 * 33;      // per-wave transposed scratch
+    static constexpr int G_FLOATS = 4 * 256;          // per-wave g[4][32] + xs[32][4]
+};
+
+struct GridArgs {
+    int ndim;
+    int64_t dims[3];
+    float lo, hi;
+    float step[3];
+};
+
+struct FusedArgs {
+    brief_siren_desc d;
+    const float *pk;
+    const float *coords;
+    const float *targets;
+    const float *weights;
+    const int64_t *idx;
+    int64_t offset;
+    int64_t n;
+    GridArgs grid;
+    int loss_kind;
+    float thr, beta, inv_count;
+    float *Z;            // [(L-2)][FP][npad]   pre-activations of layers 0..L-3
+    float *D;            // [(L-2)][FP][npad]   deltas of layers 1..L-2
+    int64_t npad;
+    float *rec;          // [gridDim.x*4][BRIEF_REC_FLOATS]
+    float *yhat_out;     // [n][cout] or NULL
+    void *out;           // forward output
+    int out_kind;
+    float scale_min, den, span, vmin;   // fused invnormalize
+};
+
+// torch.linspace as torch-CPU evaluates it (utils/dataset.py:28-32)
+__device__ __forceinline__ float lin_coord(const GridArgs &g, int a, int64_t i)
+{
+    const int64_t nn = g.dims[a];
+    if (nn == 1) return g.lo;
+    return i < nn / 2 ? __fmaf_rn(g.step[a], (float)i, g.lo) : __fmaf_rn(-g.step[a], (float)(nn - 1 - i), g.hi);
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// 16-byte buffer load: one VGPR byte offset per lane + a scalar byte offset, so no per-block
+// 64-bit address VGPRs exist for the compiler to hoist and spill (cdna_hip_programming.md T8).
+__device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t rs, int voff, int soff)
+{
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t rs, int voff, int soff)
+{
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+}
+__device__ __forceinline__ void bstore1(float v, __amdgpu_buffer_rsrc_t rs, int voff, int soff)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, voff, soff, 0);
+}
+
+// One layer's GEMM for the feature tiles this wave owns:  acc[t] += A(mt,:) * image.
+// A fragments stream from the packed weight buffer (L2 resident) PD (kt,q)-steps ahead of use.
+template <int NT>
+__device__ __forceinline__ void chain(f32x16 (&acc)[KCfg<NT>::MTW], __amdgpu_buffer_rsrc_t rs, int soff_layer /*bytes*/,
+                                      const float4 *Xs, int wm, int lane)
+{
+    using K = KCfg<NT>;
+    constexpr int NIT = NT * 4;
+    constexpr int PD = NIT < 4 ? NIT : 4;
+    const int voff = lane * 16;
+    const int soff_w = soff_layer + wm * (NT * 4 * 1024);
+    float4 areg[NIT][K::MTW];
+    float4 breg[NIT];
+#pragma unroll
+    for (int it = 0; it < PD; ++it)
+#pragma unroll
+        for (int t = 0; t < K::MTW; ++t)
+            if (K::EXACT || wm + K::WM * t < NT) areg[it][t] = bload4(rs, voff, soff_w + (K::WM * t * NT * 4 + it) * 1024);
+    breg[0] = Xs[lane];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        if (it + PD < NIT) {
+#pragma unroll
+            for (int t = 0; t < K::MTW; ++t)
+                if (K::EXACT || wm + K::WM * t < NT)
+                    areg[it + PD][t] = bload4(rs, voff, soff_w + (K::WM * t * NT * 4 + it + PD) * 1024);
+        }
+        if (it + 1 < NIT) breg[it + 1] = Xs[(it + 1) * 64 + lane];
+        // pin the prefetch above this step's MFMAs: left alone, the scheduler sinks each load to
+        // just before its use (one register set, vmcnt(0) per step, L2 latency fully exposed)
+        __builtin_amdgcn_sched_barrier(0);
+        const float4 b = breg[it];
+#pragma unroll
+        for (int t = 0; t < K::MTW; ++t) {
+            if (K::EXACT || wm + K::WM * t < NT) {
+                const float4 a = areg[it][t];
+                acc[t] = MFMA(a.x, b.x, acc[t]);
+                acc[t] = MFMA(a.y, b.y, acc[t]);
+                acc[t] = MFMA(a.z, b.z, acc[t]);
+                acc[t] = MFMA(a.w, b.w, acc[t]);
+            }
+        }
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void write_image(float4 *Xs, const f32x16 (&h)[KCfg<NT>::MTW], int wm, int lane)
+{
+    using K = KCfg<NT>;
+#pragma unroll
+    for (int t = 0; t < K::MTW; ++t) {
+        const int mt = wm + K::WM * t;
+        if (K::EXACT || mt < NT) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                Xs[(mt * 4 + q) * 64 + lane] = make_float4(h[t][4 * q], h[t][4 * q + 1], h[t][4 * q + 2], h[t][4 * q + 3]);
+        }
+    }
+}
+
+template <int NT, bool TRAIN>
+__global__ __launch_bounds__(256, 2) void k_fused(const FusedArgs a)
+{
+    using K = KCfg<NT>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float4 *X = reinterpret_cast<float4 *>(smem);
+    float *T = smem + K::XS_FLOATS;
+    float *G = T + K::T_FLOATS;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hi = lane >> 5, ln = lane & 31;
+    const int wm = wave % K::WM, ws = wave / K::WM;
+    const brief_siren_desc &d = a.d;
+    const int L = d.layers, cin = d.cin, cout = d.cout;
+    const int64_t npad = a.npad;
+    const float *pk = a.pk;
+    float4 *Xs = X + ws * (NT * 256);
+    float *Tw = T + wave * (64 * 33);
+    float *Gw = G + wave * 256;
+    const float4 *W0p = reinterpret_cast<const float4 *>(pk + brief_pk_w0(d));
+    const float *headp = pk + brief_pk_head(d);   // Whp[4][FP] then bhp[4]
+    const __amdgpu_buffer_rsrc_t rs_pk =
+        __builtin_amdgcn_make_buffer_rsrc((void *)pk, 0, (int)(brief_pk_count(d) * 4), 0x00020000);
+    const int stash_bytes = (int)((int64_t)K::FP * npad * 4);   // one [FP][npad] panel (host checks < 2^31)
+    const int row_bytes = (int)(npad * 4);
+
+    // persistent skinny-gradient accumulators (lane <-> local feature)
+    float acc0[4] = {0.f, 0.f, 0.f, 0.f};
+    float accWh[4] = {0.f, 0.f, 0.f, 0.f};
+    float accbh[4] = {0.f, 0.f, 0.f, 0.f};
+    float lsum = 0.f;
+
+    const int64_t wg_samples = 32 * K::WS;
+    const int64_t ntiles = (a.n + wg_samples - 1) / wg_samples;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t n0 = (tile * K::WS + ws) * 32;
+        const int64_t n = n0 + ln;
+        const bool valid = n < a.n;
+        // ---- sample inputs (every wave of the sample tile computes them; they are tiny)
+        int64_t j = 0;
+        if (valid) j = a.idx ? a.idx[n] : n + a.offset;
+        float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+        if (valid) {
+            if (a.coords) {
+                x0 = a.coords[j * cin];
+                x1 = a.coords[j * cin + 1];
+                if (cin == 3) x2 = a.coords[j * cin + 2];
+            } else if (cin == 3) {
+                const int64_t iw = j % a.grid.dims[2], t2 = j / a.grid.dims[2];
+                const int64_t ih = t2 % a.grid.dims[1], id = t2 / a.grid.dims[1];
+                x0 = lin_coord(a.grid, 0, id);
+                x1 = lin_coord(a.grid, 1, ih);
+                x2 = lin_coord(a.grid, 2, iw);
+            } else {
+                const int64_t iw = j % a.grid.dims[1], ih = j / a.grid.dims[1];
+                x0 = lin_coord(a.grid, 0, ih);
+                x1 = lin_coord(a.grid, 1, iw);
+            }
+        }
+        f32x16 acc[K::MTW];
+        f32x16 creg[K::MTW];   // w*cos(w z) of the last sine layer (TRAIN)
+        f32x16 hreg[K::MTW];
+#pragma unroll
+        for (int t = 0; t < K::MTW; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { creg[t][r] = 0.f; hreg[t][r] = 0.f; }
+        // ---- layer 0: z0 = W0 x + b0 as two K=2 MFMAs ([x0 x1 | x2 1] against W0p rows)
+        {
+            const float b0 = hi ? x1 : x0;
+            const float b1 = hi ? 1.0f : x2;
+#pragma unroll
+            for (int t = 0; t < K::MTW; ++t) {
+                const int mt = wm + K::WM * t;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+                if (K::EXACT || mt < NT) {
+                    const float4 w = W0p[32 * mt + ln];
+                    acc[t] = MFMA(hi ? w.y : w.x, b0, acc[t]);
+                    acc[t] = MFMA(hi ? w.w : w.z, b1, acc[t]);
+                }
+            }
+        }
+        // ---- sine layers 0 .. L-2
+        for (int l = 0; l <= L - 2; ++l) {
+            const float om = l == 0 ? d.w0_first : d.w0_hidden;
+            const bool last = (l == L - 2);
+            if (l > 0) {
+                const float *blk = pk + brief_pk_hidden(d, l);
+                const float *bp = blk + 2 * K::FP * K::FP;
+#pragma unroll
+                for (int t = 0; t < K::MTW; ++t) {
+                    const int mt = wm + K::WM * t;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (K::EXACT || mt < NT) bb = *reinterpret_cast<const float4 *>(bp + 32 * mt + 8 * q + 4 * hi);
+                        acc[t][4 * q] = bb.x; acc[t][4 * q + 1] = bb.y; acc[t][4 * q + 2] = bb.z; acc[t][4 * q + 3] = bb.w;
+                    }
+                }
+                chain<NT>(acc, rs_pk, (int)(brief_pk_hidden(d, l) * 4), Xs, wm, lane);
+                __syncthreads();   // every wave is done reading the previous image
+            }
+            // epilogue: stash z, h = sin(om z) (+ c = om cos(om z) on the last sine layer)
+#pragma unroll
+            for (int t = 0; t < K::MTW; ++t) {
+                const int mt = wm + K::WM * t;
+                if (K::EXACT || mt < NT) {
+                    if (TRAIN && !last) {
+                        const __amdgpu_buffer_rsrc_t rz =
+                            __builtin_amdgcn_make_buffer_rsrc((void *)(a.Z + (int64_t)l * K::FP * npad), 0, stash_bytes, 0x00020000);
+                        const int voff = (int)(n * 4) + hi * 4 * row_bytes;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            bstore1(acc[t][r], rz, voff, (32 * mt + (r & 3) + 8 * (r >> 2)) * row_bytes);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float s, c;
+                        brief_sincosf(om * acc[t][r], &s, &c);
+                        hreg[t][r] = s;
+                        if (TRAIN && last) creg[t][r] = om * c;
+                    }
+                }
+            }
+            write_image<NT>(Xs, hreg, wm, lane);
+            __syncthreads();
+        }
+        // ---- head (every wave evaluates it for its sample tile; F MACs per sample)
+        float zo[4], yh[4], g[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            zo[c] = 0.f; yh[c] = 0.f; g[c] = 0.f;
+            if (c < cout) {
+                float p = 0.f;
+                const float *wrow = headp + c * K::FP;
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 hv = Xs[(kt * 4 + q) * 64 + lane];
+                        const float4 wv = *reinterpret_cast<const float4 *>(wrow + 32 * kt + 8 * q + 4 * hi);
+                        p = __fmaf_rn(wv.x, hv.x, p); p = __fmaf_rn(wv.y, hv.y, p);
+                        p = __fmaf_rn(wv.z, hv.z, p); p = __fmaf_rn(wv.w, hv.w, p);
+                    }
+                }
+                p += __shfl_xor(p, 32);
+                zo[c] = p + headp[4 * K::FP + c];
+                yh[c] = d.output_act ? brief_sinf(d.w0_hidden * zo[c]) : zo[c];
+            }
+        }
+        if (!TRAIN) {
+            if (wm == 0 && hi == 0 && valid) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (c >= cout) break;
+                    if (a.out_kind == BRIEF_OUT_F32) {
+                        reinterpret_cast<float *>(a.out)[n * cout + c] = yh[c];
+                    } else {
+                        // utils/io.py:136-147: separate roundings, truncating cast
+                        float t = __fsub_rn(yh[c], a.scale_min);
+                        t = __fdiv_rn(t, a.den);
+                        t = fminf(fmaxf(t, 0.f), 1.f);
+                        const float u = __fadd_rn(__fmul_rn(t, a.span), a.vmin);
+                        if (a.out_kind == BRIEF_OUT_U16) reinterpret_cast<uint16_t *>(a.out)[n * cout + c] = (uint16_t)(int)u;
+                        else reinterpret_cast<uint8_t *>(a.out)[n * cout + c] = (uint8_t)(int)u;
+                    }
+                }
+            }
+            __syncthreads();   // image is re-used by the next tile
+            continue;
+        }
+        // ---- loss and dloss/dyhat (main.py:176-191)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c < cout && valid) {
+                const float y = a.targets[j * cout + c];
+                float we = a.weights ? a.weights[j * cout + c] : 1.0f;
+                if (a.thr != 0.f && yh[c] <= a.thr) we = 1.0f;
+                const float df = yh[c] - y;
+                float li, gi;
+                if (a.loss_kind == BRIEF_LOSS_L2) { li = df * df; gi = 2.0f * df; }
+                else {
+                    const float ad = fabsf(df);
+                    if (ad < a.beta) { li = 0.5f * df * df / a.beta; gi = df / a.beta; }
+                    else { li = ad - 0.5f * a.beta; gi = df < 0.f ? -1.0f : 1.0f; }
+                }
+                if (wm == 0 && hi == 0) lsum += li * we;
+                g[c] = gi * we * a.inv_count;
+                if (d.output_act) g[c] *= d.w0_hidden * brief_cosf(d.w0_hidden * zo[c]);
+                if (a.yhat_out && wm == 0 && hi == 0) a.yhat_out[n * cout + c] = yh[c];
+            }
+        }
+        // ---- head gradients: transpose own h tiles through LDS, lane <-> local feature
+#pragma unroll
+        for (int t = 0; t < K::MTW; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Tw[(32 * t + ROWMAP(r, hi)) * 33 + ln] = hreg[t][r];
+        }
+        if (hi == 0) *reinterpret_cast<float4 *>(Gw + ln * 4) = make_float4(g[0], g[1], g[2], g[3]);
+        else *reinterpret_cast<float4 *>(Gw + 128 + ln * 4) = make_float4(x0, x1, x2, 1.0f);
+        __syncthreads();
+        {
+            float4 sW = make_float4(0.f, 0.f, 0.f, 0.f), sb = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float *trow = Tw + lane * 33;
+#pragma unroll 4
+            for (int s = 0; s < 32; ++s) {
+                const float hv = trow[s];
+                const float4 gv = *reinterpret_cast<const float4 *>(Gw + s * 4);
+                sW.x = __fmaf_rn(hv, gv.x, sW.x); sW.y = __fmaf_rn(hv, gv.y, sW.y);
+                sW.z = __fmaf_rn(hv, gv.z, sW.z); sW.w = __fmaf_rn(hv, gv.w, sW.w);
+                sb.x += gv.x; sb.y += gv.y; sb.z += gv.z; sb.w += gv.w;
+            }
+            if (lane < 32 * K::MTW) { accWh[0] += sW.x; accWh[1] += sW.y; accWh[2] += sW.z; accWh[3] += sW.w; }
+            accbh[0] += sb.x; accbh[1] += sb.y; accbh[2] += sb.z; accbh[3] += sb.w;
+        }
+        // ---- delta of the last sine layer: c * (Wh^T g)
+        f32x16 dl[K::MTW];
+#pragma unroll
+        for (int t = 0; t < K::MTW; ++t) {
+            const int mt = wm + K::WM * t;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dl[t][r] = 0.f;
+            if (K::EXACT || mt < NT) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if (c < cout) {
+                            const float4 wv = *reinterpret_cast<const float4 *>(headp + c * K::FP + 32 * mt + 8 * q + 4 * hi);
+                            sacc.x = __fmaf_rn(wv.x, g[c], sacc.x); sacc.y = __fmaf_rn(wv.y, g[c], sacc.y);
+                            sacc.z = __fmaf_rn(wv.z, g[c], sacc.z); sacc.w = __fmaf_rn(wv.w, g[c], sacc.w);
+                        }
+                    }
+                    dl[t][4 * q] = creg[t][4 * q] * sacc.x; dl[t][4 * q + 1] = creg[t][4 * q + 1] * sacc.y;
+                    dl[t][4 * q + 2] = creg[t][4 * q + 2] * sacc.z; dl[t][4 * q + 3] = creg[t][4 * q + 3] * sacc.w;
+                }
+            }
+        }
+        // ---- dgrad chain: layers L-2 .. 1
+        for (int l = L - 2; l >= 1; --l) {
+            // stash delta_l for the weight-gradient GEMM and publish it as the B image
+            const __amdgpu_buffer_rsrc_t rd =
+                __builtin_amdgcn_make_buffer_rsrc((void *)(a.D + (int64_t)(l - 1) * K::FP * npad), 0, stash_bytes, 0x00020000);
+            const int voff_s = (int)(n * 4) + hi * 4 * row_bytes;
+#pragma unroll
+            for (int t = 0; t < K::MTW; ++t) {
+                const int mt = wm + K::WM * t;
+                if (K::EXACT || mt < NT) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        bstore1(dl[t][r], rd, voff_s, (32 * mt + (r & 3) + 8 * (r >> 2)) * row_bytes);
+                }
+            }
+            __syncthreads();   // head / previous chain finished with the image
+            write_image<NT>(Xs, dl, wm, lane);
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < K::MTW; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+            chain<NT>(acc, rs_pk, (int)((brief_pk_hidden(d, l) + K::FP * K::FP) * 4), Xs, wm, lane);
+            // delta_{l-1} = acc * om cos(om z_{l-1}), z re-read from the stash
+            const float om = (l - 1) == 0 ? d.w0_first : d.w0_hidden;
+            const __amdgpu_buffer_rsrc_t rzp =
+                __builtin_amdgcn_make_buffer_rsrc((void *)(a.Z + (int64_t)(l - 1) * K::FP * npad), 0, stash_bytes, 0x00020000);
+#pragma unroll
+            for (int t = 0; t < K::MTW; ++t) {
+                const int mt = wm + K::WM * t;
+                if (K::EXACT || mt < NT) {
+                    float zr[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) zr[r] = bload1(rzp, voff_s, (32 * mt + (r & 3) + 8 * (r >> 2)) * row_bytes);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dl[t][r] = acc[t][r] * om * brief_cosf(om * zr[r]);
+                }
+            }
+        }
+        // ---- first-layer gradients from delta_0 (lane <-> local feature)
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < K::MTW; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Tw[(32 * t + ROWMAP(r, hi)) * 33 + ln] = dl[t][r];
+        }
+        __syncthreads();
+        {
+            float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float *trow = Tw + lane * 33;
+#pragma unroll 4
+            for (int s = 0; s < 32; ++s) {
+                const float dv = trow[s];
+                const float4 xv = *reinterpret_cast<const float4 *>(Gw + 128 + s * 4);
+                s0.x = __fmaf_rn(dv, xv.x, s0.x); s0.y = __fmaf_rn(dv, xv.y, s0.y);
+                s0.z = __fmaf_rn(dv, xv.z, s0.z); s0.w = __fmaf_rn(dv, xv.w, s0.w);
+            }
+            if (lane < 32 * K::MTW) { acc0[0] += s0.x; acc0[1] += s0.y; acc0[2] += s0.z; acc0[3] += s0.w; }
+        }
+        __syncthreads();
+    }
+    if (TRAIN) {
+        float *rec = a.rec + ((int64_t)blockIdx.x * 4 + wave) * BRIEF_REC_FLOATS;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            rec[lane * 4 + c] = acc0[c];          // dW0[f_local][x0,x1,x2,bias]
+            rec[256 + c * 64 + lane] = accWh[c];  // dWh[c][f_local]
+        }
+        for (int off = 32; off >= 1; off >>= 1) lsum += __shfl_xor(lsum, off);
+        if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) rec[512 + c] = accbh[c];
+            rec[516] = lsum;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight-gradient GEMM: dW_l[fo][fi] = sum_n D_l[fo][n] * sin(w Z_{l-1}[fi][n]),  db_l = sum_n D_l
+struct WgradArgs {
+    brief_siren_desc d;
+    const float *Z;
+    const float *D;
+    int64_t npad;
+    int nsplit;
+    float *slabs;       // [(L-2)][nsplit][FP*FP + FP]
+};
+
+template <int NT>
+__global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
+{
+    constexpr int FP = 32 * NT;
+    constexpr int WMk = 2, WNk = 4;
+    constexpr int TM = (NT + WMk - 1) / WMk, TN = (NT + WNk - 1) / WNk;
+    constexpr int LDSW = 36;                       // row stride (floats): conflict-free ds_read_b128
+    constexpr int NLD = (FP * 8 + 511) / 512;      // float4 loads per thread per operand per chunk
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *As = smem, *Bs = smem + FP * LDSW;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, ln = lane & 31;
+    const int wmk = wave / WNk, wnk = wave % WNk;
+    const int l = 1 + blockIdx.x / a.nsplit;       // hidden layer 1..L-2
+    const int split = blockIdx.x % a.nsplit;
+    const int64_t nchunks = a.npad / 32;
+    const int64_t c0 = nchunks * split / a.nsplit, c1 = nchunks * (split + 1) / a.nsplit;
+    const float om = (l - 1) == 0 ? a.d.w0_first : a.d.w0_hidden;
+    const float *Dl = a.D + (int64_t)(l - 1) * FP * a.npad;
+    const float *Zl = a.Z + (int64_t)(l - 1) * FP * a.npad;
+
+    f32x16 acc[TM][TN];
+    float dbacc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        dbacc[i] = 0.f;
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
+    }
+    float4 ra[NLD], rb[NLD];
+    auto issue = [&](int64_t c) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = tid + 512 * i;           // float4 slot: row = e/8, col4 = e%8
+            if (e < FP * 8) {
+                const int64_t off = (int64_t)(e >> 3) * a.npad + c * 32 + (e & 7) * 4;
+                ra[i] = *reinterpret_cast<const float4 *>(Dl + off);
+                rb[i] = *reinterpret_cast<const float4 *>(Zl + off);
+            }
+        }
+    };
+    if (c0 < c1) issue(c0);
+    for (int64_t c = c0; c < c1; ++c) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = tid + 512 * i;
+            if (e < FP * 8) {
+                const int o = (e >> 3) * LDSW + (e & 7) * 4;
+                *reinterpret_cast<float4 *>(As + o) = ra[i];
+                float4 h;
+                h.x = brief_sinf(om * rb[i].x); h.y = brief_sinf(om * rb[i].y);
+                h.z = brief_sinf(om * rb[i].z); h.w = brief_sinf(om * rb[i].w);
+                *reinterpret_cast<float4 *>(Bs + o) = h;
+            }
+        }
+        __syncthreads();
+        if (c + 1 < c1) issue(c + 1);
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            float4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int mt = wmk * TM + i;
+                af[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (mt < NT) af[i] = *reinterpret_cast<const float4 *>(As + (32 * mt + ln) * LDSW + 8 * gq + 4 * hi);
+                if (wnk == 0) dbacc[i] += (af[i].x + af[i].y) + (af[i].z + af[i].w);
+            }
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) {
+                const int nt = wnk * TN + jn;
+                bf[jn] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (nt < NT) bf[jn] = *reinterpret_cast<const float4 *>(Bs + (32 * nt + ln) * LDSW + 8 * gq + 4 * hi);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn) {
+                    if (wmk * TM + i < NT && wnk * TN + jn < NT) {
+                        acc[i][jn] = MFMA(af[i].x, bf[jn].x, acc[i][jn]);
+                        acc[i][jn] = MFMA(af[i].y, bf[jn].y, acc[i][jn]);
+                        acc[i][jn] = MFMA(af[i].z, bf[jn].z, acc[i][jn]);
+                        acc[i][jn] = MFMA(af[i].w, bf[jn].w, acc[i][jn]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float *slab = a.slabs + ((int64_t)(l - 1) * a.nsplit + split) * ((int64_t)FP * FP + FP);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int mt = wmk * TM + i;
+        if (mt < NT) {
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) {
+                const int nt = wnk * TN + jn;
+                if (nt < NT) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        slab[(int64_t)(32 * mt + ROWMAP(r, hi)) * FP + 32 * nt + ln] = acc[i][jn][r];
+                }
+            }
+            if (wnk == 0) {
+                const float tot = dbacc[i] + __shfl_xor(dbacc[i], 32);
+                if (hi == 0) slab[(int64_t)FP * FP + 32 * mt + ln] = tot;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// deterministic reduction of the partials into the canonical gradient buffer
+struct ReduceArgs {
+    brief_siren_desc d;
+    const float *rec;     // [nrec_wg*4][REC]
+    int nrec_wg;
+    const float *slabs;
+    int nsplit;
+    float *grads;
+    float *loss_out;
+    float inv_count;
+};
+
+// blocks [0, nb_hidden): one thread per hidden-layer parameter, nsplit slab terms each.
+// blocks [nb_hidden, ...): one WAVE per first-layer / head parameter (and one for the loss): these sum
+// over up to 2048 per-wave records, which a single thread would walk at one L2 latency per term.
+__global__ __launch_bounds__(256) void k_reduce(const ReduceArgs a, int nb_hidden)
+{
+    const brief_siren_desc &d = a.d;
+    const int F = d.features, cin = d.cin, cout = d.cout;
+    const int NT = brief_nt(d), FP = 32 * NT, WM = brief_wm(NT), WS = brief_ws(NT);
+    const int64_t off_head = brief_canon_head_off(d);
+    const int64_t l0_count = (int64_t)F * cin + F;
+    if ((int)blockIdx.x < nb_hidden) {
+        const int64_t hcount = off_head - l0_count;
+        const int64_t hidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (hidx >= hcount) return;
+        const int64_t per = (int64_t)F * F + F;
+        const int l = 1 + (int)(hidx / per);
+        const int64_t r = hidx % per;
+        int64_t so;
+        if (r < (int64_t)F * F) so = (r / F) * FP + (r % F);
+        else so = (int64_t)FP * FP + (r - (int64_t)F * F);
+        const int64_t slab_sz = (int64_t)FP * FP + FP;
+        const float *base = a.slabs + (int64_t)(l - 1) * a.nsplit * slab_sz + so;
+        float s = 0.f;
+#pragma unroll 8
+        for (int sp = 0; sp < a.nsplit; ++sp) s += base[(int64_t)sp * slab_sz];
+        a.grads[l0_count + hidx] = s;
+        return;
+    }
+    // ---- skinny parameters: wave w of this block handles item (blockIdx - nb_hidden)*4 + w
+    const int lane = threadIdx.x & 63;
+    const int64_t item = (int64_t)(blockIdx.x - nb_hidden) * 4 + (threadIdx.x >> 6);
+    const int64_t head_count = (int64_t)cout * F + cout;
+    const int nrec = a.nrec_wg * WS;                 // records that carry a given feature tile / the loss
+    if (item > l0_count + head_count) return;
+    int slot, wmo = 0;
+    if (item == l0_count + head_count) {
+        slot = 516;                                   // loss (waves with wm == 0)
+    } else if (item < l0_count) {
+        int o, c;
+        if (item < (int64_t)F * cin) { o = (int)(item / cin); c = (int)(item % cin); }
+        else { o = (int)(item - (int64_t)F * cin); c = 3; }
+        slot = (((o >> 5) / WM) * 32 + (o & 31)) * 4 + c;
+        wmo = (o >> 5) % WM;
+    } else {
+        const int64_t r = item - l0_count;
+        if (r < (int64_t)cout * F) {
+            const int c = (int)(r / F), o = (int)(r % F);
+            slot = 256 + c * 64 + ((o >> 5) / WM) * 32 + (o & 31);
+            wmo = (o >> 5) % WM;
+        } else {
+            slot = 512 + (int)(r - (int64_t)cout * F);
+        }
+    }
+    // record index of (wg, ws) for this wm: (wg*4 + ws*WM + wmo); enumerate q = wg*WS + ws
+    float s = 0.f;
+    for (int q = lane; q < nrec; q += 64) {
+        const int wg = q / WS, w = q % WS;
+        s += a.rec[((int64_t)wg * 4 + w * WM + wmo) * BRIEF_REC_FLOATS + slot];
+    }
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) {
+        if (item == l0_count + head_count) *a.loss_out = s * a.inv_count;
+        else if (item < l0_count) a.grads[item] = s;
+        else a.grads[off_head + (item - l0_count)] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// optimizer: same arithmetic, in the same order, as oracle_optim_step (torch single-tensor rules)
+__global__ void k_optim(int kind, float *__restrict__ p, const float *__restrict__ g, float *__restrict__ s1,
+                        float *__restrict__ s2, int64_t n, float w1, float fb2, float w2, float feps,
+                        float nstep, float bc2s)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    if (kind == BRIEF_OPT_ADAMAX) {
+        const float m = __fmaf_rn(w1, __fsub_rn(gi, s1[i]), s1[i]);
+        const float ua = __fmul_rn(s2[i], fb2), ub = __fadd_rn(fabsf(gi), feps);
+        const float u = ua > ub ? ua : ub;
+        s1[i] = m; s2[i] = u;
+        p[i] = __fadd_rn(p[i], __fdiv_rn(__fmul_rn(nstep, m), u));
+    } else if (kind == BRIEF_OPT_ADAM) {
+        const float m = __fmaf_rn(w1, __fsub_rn(gi, s1[i]), s1[i]);
+        const float v = __fadd_rn(__fmul_rn(s2[i], fb2), __fmul_rn(w2, __fmul_rn(gi, gi)));
+        s1[i] = m; s2[i] = v;
+        const float den = __fadd_rn(__fdiv_rn(sqrtf(v), bc2s), feps);   // sqrtf: correctly rounded (hipcc default)
+        p[i] = __fadd_rn(p[i], __fdiv_rn(__fmul_rn(nstep, m), den));
+    } else {
+        p[i] = __fadd_rn(p[i], __fmul_rn(nstep, gi));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void k_repack(const brief_siren_desc d, const float *__restrict__ params, float *__restrict__ pk)
+{
+    const int F = d.features, cin = d.cin, cout = d.cout, L = d.layers;
+    const int NT = brief_nt(d), FP = 32 * NT;
+    const int64_t total = brief_pk_count(d);
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    float v = 0.f;
+    const int64_t head = brief_pk_head(d);
+    if (e < (int64_t)FP * 4) {
+        const int f = (int)(e >> 2), c = (int)(e & 3);
+        if (f < F) {
+            if (c < cin) v = params[(int64_t)f * cin + c];
+            else if (c == 3) v = params[(int64_t)F * cin + f];
+        }
+    } else if (e < head) {
+        const int64_t hs = brief_pk_hidden_stride(d);
+        const int l = 1 + (int)((e - (int64_t)FP * 4) / hs);
+        int64_t r = (e - (int64_t)FP * 4) % hs;
+        const float *W = params + brief_canon_hidden_off(d, l);
+        const float *b = W + (int64_t)F * F;
+        if (r < 2 * (int64_t)FP * FP) {
+            const bool bwd = r >= (int64_t)FP * FP;
+            if (bwd) r -= (int64_t)FP * FP;
+            const int jj = (int)(r & 3), lanei = (int)((r >> 2) & 63), q = (int)((r >> 8) & 3);
+            const int kt = (int)((r >> 10) % NT), mt = (int)((r >> 10) / NT);
+            const int row = 32 * mt + (lanei & 31);
+            const int col = 32 * kt + 8 * q + 4 * (lanei >> 5) + jj;
+            if (row < F && col < F) v = bwd ? W[(int64_t)col * F + row] : W[(int64_t)row * F + col];
+        } else {
+            const int f = (int)(r - 2 * (int64_t)FP * FP);
+            if (f < F) v = b[f];
+        }
+    } else {
+        const int64_t r = e - head;
+        const float *Wh = params + brief_canon_head_off(d);
+        if (r < 4 * (int64_t)FP) {
+            const int c = (int)(r / FP), f = (int)(r % FP);
+            if (c < cout && f < F) v = Wh[(int64_t)c * F + f];
+        } else {
+            const int c = (int)(r - 4 * (int64_t)FP);
+            if (c < cout) v = Wh[(int64_t)cout * F + c];
+        }
+    }
+    (void)L;
+    pk[e] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 voxel-index stream (stands in for the CPU torch.randint of main.py:156)
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1)
+{
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+__global__ void k_sample(int64_t *idx, int64_t n, uint64_t pop, uint64_t seed, uint64_t step)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t c[4] = {(uint32_t)i, (uint32_t)((uint64_t)i >> 32), (uint32_t)step, (uint32_t)(step >> 32)};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const uint64_t r64 = ((uint64_t)c[0] << 32) | c[1];
+    // unbiased enough for pop << 2^64 (multiply-shift); pop <= 2^40 here
+    idx[i] = (int64_t)__umul64hi(r64, pop);
+}
+
+__global__ void k_sse_u16(const uint16_t *__restrict__ x, const uint16_t *__restrict__ y, int64_t n, unsigned long long *acc)
+{
+    unsigned long long s = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const long long dff = (long long)x[i] - (long long)y[i];
+        s += (unsigned long long)(dff * dff);
+    }
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0) atomicAdd(acc, s);   // integer: order-independent, exact
+}
+
+__global__ void k_u64_to_double(const unsigned long long *acc, double *out) { *out = (double)*acc; }
+
+// =============================================================================================
+// C-ABI
+static thread_local char g_err[512] = "";
+static int fail(int code, const char *fmt, const char *detail = "")
+{
+    snprintf(g_err, sizeof(g_err), fmt, detail);
+    return code;
+}
+#define HIP_TRY(x)                                                                  \
+    do {                                                                            \
+        hipError_t e_ = (x);                                                        \
+        if (e_ != hipSuccess) return fail(BRIEF_ERR_LAUNCH, #x ": %s", hipGetErrorString(e_)); \
+    } while (0)
+
+static int check_desc(const brief_siren_desc *d)
+{
+    if (!d) return fail(BRIEF_ERR_INVALID, "null desc");
+    if (d->cin != 2 && d->cin != 3) return fail(BRIEF_ERR_INVALID, "coords_channel must be 2 or 3");
+    if (d->cout < 1 || d->cout > 4) return fail(BRIEF_ERR_INVALID, "data_channel must be 1..4");
+    if (d->layers < 2) return fail(BRIEF_ERR_INVALID, "layers must be >= 2");
+    if (d->features < 1 || d->features > 32 * BRIEF_MAX_NT)
+        return fail(BRIEF_ERR_INVALID, "features must be 1..256 on the fused fp32 path");
+    return 0;
+}
+
+// optional live timing of the dominant kernel (bench.py roofline leg): event pairs recorded on the
+// caller's stream around every k_fused<TRAIN> launch while enabled.
+static const int kProfSlots = 4096;
+static bool g_prof_on = false;
+static int g_prof_n = 0;
+static hipEvent_t g_prof_ev[2 * kProfSlots];
+static bool g_prof_init = false;
+
+static const int kMaxFusedGrid = 512;   // 2 resident workgroups per CU on 256 CUs
+static const int kWgradBlocks = 256;
+
+static int fused_grid(const brief_siren_desc &d, int64_t n)
+{
+    const int nt = brief_nt(d);
+    const int64_t tiles = (n + brief_wg_samples(nt) - 1) / brief_wg_samples(nt);
+    return (int)(tiles < kMaxFusedGrid ? (tiles > 0 ? tiles : 1) : kMaxFusedGrid);
+}
+static int wgrad_splits(const brief_siren_desc &d, int64_t n)
+{
+    const int hidden = d.layers - 2;
+    if (hidden <= 0) return 0;
+    const int64_t nchunks = brief_npad(brief_nt(d), n) / 32;
+    int64_t s = kWgradBlocks / hidden;
+    if (s < 1) s = 1;
+    if (s > nchunks) s = nchunks;
+    return (int)s;
+}
+
+struct WsLayout { int64_t z, dd, rec, slabs, total; };
+static WsLayout ws_layout(const brief_siren_desc &d, int64_t n)
+{
+    const int nt = brief_nt(d);
+    const int64_t FP = 32 * nt, npad = brief_npad(nt, n), hidden = d.layers - 2 > 0 ? d.layers - 2 : 0;
+    WsLayout w;
+    w.z = 0;
+    w.dd = w.z + hidden * FP * npad;
+    w.rec = w.dd + hidden * FP * npad;
+    w.slabs = w.rec + (int64_t)kMaxFusedGrid * 4 * BRIEF_REC_FLOATS;
+    w.total = w.slabs + hidden * (int64_t)wgrad_splits(d, n) * (FP * FP + FP);
+    return w;
+}
+
+extern "C" {
+
+int brief_version(void) { return BRIEF_VERSION; }
+const char *brief_last_error(void) { return g_err; }
+
+int64_t brief_param_count(const brief_siren_desc *d) { return check_desc(d) ? -1 : brief_canon_count(*d); }
+int64_t brief_packed_count(const brief_siren_desc *d) { return check_desc(d) ? -1 : brief_pk_count(*d); }
+int64_t brief_train_workspace_bytes(const brief_siren_desc *d, int64_t n)
+{
+    if (check_desc(d) || n < 1) return -1;
+    return ws_layout(*d, n).total * (int64_t)sizeof(float);
+}
+
+int brief_siren_repack(const brief_siren_desc *d, const float *params, float *packed, void *stream)
+{
+    if (int rc = check_desc(d)) return rc;
+    if (!params || !packed) return fail(BRIEF_ERR_INVALID, "null buffer");
+    const int64_t total = brief_pk_count(*d);
+    hipLaunchKernelGGL(k_repack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *d, params, packed);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}   // extern "C" (helpers below need C++ linkage)
+
+static void fill_grid(GridArgs &g, const brief_grid_desc *grid)
+{
+    memset(&g, 0, sizeof(g));
+    if (!grid) return;
+    g.ndim = grid->ndim;
+    g.lo = grid->lo; g.hi = grid->hi;
+    for (int a = 0; a < 3; ++a) {
+        g.dims[a] = a < grid->ndim ? grid->dims[a] : 1;
+        g.step[a] = g.dims[a] > 1 ? (grid->hi - grid->lo) / (float)(g.dims[a] - 1) : 0.f;
+    }
+}
+
+template <bool TRAIN>
+static int launch_fused(const FusedArgs &fa, int grid, hipStream_t st)
+{
+    const int nt = brief_nt(fa.d);
+#define BRIEF_CASE(NTV)                                                                                  \
+    case NTV: {                                                                                          \
+        using K = KCfg<NTV>;                                                                             \
+        const size_t lds = sizeof(float) * (K::XS_FLOATS + (TRAIN ? K::T_FLOATS + K::G_FLOATS : 0));     \
+        hipLaunchKernelGGL((k_fused<NTV, TRAIN>), dim3(grid), dim3(256), lds, st, fa);                   \
+        break;                                                                                           \
+    }
+    switch (nt) {
+        BRIEF_CASE(1) BRIEF_CASE(2) BRIEF_CASE(3) BRIEF_CASE(4)
+        BRIEF_CASE(5) BRIEF_CASE(6) BRIEF_CASE(7) BRIEF_CASE(8)
+    default: return fail(BRIEF_ERR_INVALID, "unsupported width");
+    }
+#undef BRIEF_CASE
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static int check_batch(const brief_siren_desc *d, const brief_grid_desc *grid, const brief_batch_desc *b, bool train)
+{
+    if (!b || b->n < 1) return fail(BRIEF_ERR_INVALID, "empty batch");
+    if (!b->coords) {
+        if (!grid || grid->ndim != d->cin) return fail(BRIEF_ERR_INVALID, "grid.ndim must equal coords_channel when coords is NULL");
+        for (int a = 0; a < grid->ndim; ++a)
+            if (grid->dims[a] < 1) return fail(BRIEF_ERR_INVALID, "bad grid dims");
+    }
+    if (train && !b->targets) return fail(BRIEF_ERR_INVALID, "targets required");
+    return 0;
+}
+
+extern "C" {
+
+int brief_siren_forward(const brief_siren_desc *d, const float *packed, const brief_grid_desc *grid,
+                        const brief_batch_desc *batch, void *out, int out_kind,
+                        float scale_min, float scale_max, double vmin, double vmax, void *stream)
+{
+    if (int rc = check_desc(d)) return rc;
+    if (int rc = check_batch(d, grid, batch, false)) return rc;
+    if (!packed || !out) return fail(BRIEF_ERR_INVALID, "null buffer");
+    if (out_kind < BRIEF_OUT_F32 || out_kind > BRIEF_OUT_U16) return fail(BRIEF_ERR_INVALID, "bad out_kind");
+    FusedArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.d = *d; fa.pk = packed;
+    fa.coords = batch->coords; fa.idx = batch->idx; fa.offset = batch->offset; fa.n = batch->n;
+    fill_grid(fa.grid, grid);
+    fa.npad = brief_npad(brief_nt(*d), batch->n);
+    fa.out = out; fa.out_kind = out_kind;
+    fa.scale_min = scale_min;
+    fa.den = (float)((double)scale_max - (double)scale_min);
+    fa.span = (float)(vmax - vmin);
+    fa.vmin = (float)vmin;
+    return launch_fused<false>(fa, fused_grid(*d, batch->n), (hipStream_t)stream);
+}
+
+int brief_siren_train_step(const brief_siren_desc *d, const float *packed, const brief_grid_desc *grid,
+                           const brief_batch_desc *batch, int loss_kind, float thr, float beta,
+                           float *grads, float *loss_out, float *yhat_out,
+                           void *workspace, int64_t workspace_bytes, void *stream)
+{
+    if (int rc = check_desc(d)) return rc;
+    if (int rc = check_batch(d, grid, batch, true)) return rc;
+    if (!packed || !grads || !loss_out || !workspace) return fail(BRIEF_ERR_INVALID, "null buffer");
+    if (loss_kind != BRIEF_LOSS_L2 && loss_kind != BRIEF_LOSS_SMOOTHL1) return fail(BRIEF_ERR_INVALID, "bad loss_kind");
+    const WsLayout wl = ws_layout(*d, batch->n);
+    if (workspace_bytes < wl.total * (int64_t)sizeof(float)) return fail(BRIEF_ERR_WORKSPACE, "workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float *ws = (float *)workspace;
+    const int nt = brief_nt(*d);
+    const int grid1 = fused_grid(*d, batch->n);
+    const int nsplit = wgrad_splits(*d, batch->n);
+    const float inv_count = (float)(1.0 / ((double)batch->n * d->cout));
+
+    FusedArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.d = *d; fa.pk = packed;
+    fa.coords = batch->coords; fa.targets = batch->targets; fa.weights = batch->weights;
+    fa.idx = batch->idx; fa.offset = batch->offset; fa.n = batch->n;
+    fill_grid(fa.grid, grid);
+    fa.loss_kind = loss_kind; fa.thr = thr; fa.beta = beta; fa.inv_count = inv_count;
+    fa.Z = ws + wl.z; fa.D = ws + wl.dd; fa.npad = brief_npad(nt, batch->n);
+    fa.rec = ws + wl.rec; fa.yhat_out = yhat_out;
+    const bool prof = g_prof_on && g_prof_n < kProfSlots;
+    if (prof) HIP_TRY(hipEventRecord(g_prof_ev[2 * g_prof_n], st));
+    if (int rc = launch_fused<true>(fa, grid1, st)) return rc;
+    if (prof) { HIP_TRY(hipEventRecord(g_prof_ev[2 * g_prof_n + 1], st)); ++g_prof_n; }
+
+    if (nsplit > 0) {
+        WgradArgs wa;
+        memset(&wa, 0, sizeof(wa));
+        wa.d = *d; wa.Z = fa.Z; wa.D = fa.D; wa.npad = fa.npad; wa.nsplit = nsplit; wa.slabs = ws + wl.slabs;
+        const int blocks = nsplit * (d->layers - 2);
+#define BRIEF_CASE(NTV)                                                                                    \
+    case NTV:                                                                                              \
+        hipLaunchKernelGGL((k_wgrad<NTV>), dim3(blocks), dim3(512), sizeof(float) * 2 * 32 * NTV * 36, st, wa); \
+        break;
+        switch (nt) {
+            BRIEF_CASE(1) BRIEF_CASE(2) BRIEF_CASE(3) BRIEF_CASE(4)
+            BRIEF_CASE(5) BRIEF_CASE(6) BRIEF_CASE(7) BRIEF_CASE(8)
+        }
+#undef BRIEF_CASE
+        HIP_TRY(hipGetLastError());
+    }
+    ReduceArgs ra;
+    memset(&ra, 0, sizeof(ra));
+    ra.d = *d; ra.rec = fa.rec; ra.nrec_wg = grid1; ra.slabs = ws + wl.slabs; ra.nsplit = nsplit;
+    ra.grads = grads; ra.loss_out = loss_out; ra.inv_count = inv_count;
+    const int64_t l0_count = (int64_t)d->features * d->cin + d->features;
+    const int64_t hcount = brief_canon_head_off(*d) - l0_count;
+    const int64_t skinny = l0_count + (int64_t)d->cout * d->features + d->cout + 1;   // + the loss
+    const int nb_hidden = (int)((hcount + 255) / 256);
+    const int nb_skinny = (int)((skinny + 3) / 4);
+    hipLaunchKernelGGL(k_reduce, dim3(nb_hidden + nb_skinny), dim3(256), 0, st, ra, nb_hidden);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int brief_optim_step(int kind, float *params, const float *grads, float *state1, float *state2, int64_t count,
+                     double lr, double beta1, double beta2, double eps, int64_t t, void *stream)
+{
+    if (kind < BRIEF_OPT_ADAMAX || kind > BRIEF_OPT_SGD) return fail(BRIEF_ERR_INVALID, "bad optimizer kind");
+    if (!params || !grads || count < 1 || t < 1) return fail(BRIEF_ERR_INVALID, "bad optimizer arguments");
+    if (kind != BRIEF_OPT_SGD && (!state1 || !state2)) return fail(BRIEF_ERR_INVALID, "optimizer state required");
+    // scalars prepared in double exactly as oracle_optim_step / torch do
+    float nstep, bc2s = 1.f;
+    if (kind == BRIEF_OPT_SGD) nstep = (float)(-lr);
+    else nstep = (float)(-(lr / (1.0 - pow(beta1, (double)t))));
+    if (kind == BRIEF_OPT_ADAM) bc2s = (float)sqrt(1.0 - pow(beta2, (double)t));
+    hipLaunchKernelGGL(k_optim, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, kind, params, grads,
+                       state1, state2, count, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, nstep, bc2s);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int brief_profile_enable(int on)
+{
+    if (on && !g_prof_init) {
+        for (int i = 0; i < 2 * kProfSlots; ++i) HIP_TRY(hipEventCreate(&g_prof_ev[i]));
+        g_prof_init = true;
+    }
+    g_prof_on = on != 0;
+    g_prof_n = 0;
+    return 0;
+}
+
+int brief_profile_fused(double *total_ms, int64_t *launches)
+{
+    if (!total_ms || !launches) return fail(BRIEF_ERR_INVALID, "null output");
+    double tot = 0.0;
+    for (int i = 0; i < g_prof_n; ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventSynchronize(g_prof_ev[2 * i + 1]));
+        HIP_TRY(hipEventElapsedTime(&ms, g_prof_ev[2 * i], g_prof_ev[2 * i + 1]));
+        tot += ms;
+    }
+    *total_ms = tot;
+    *launches = g_prof_n;
+    return 0;
+}
+
+int brief_sample_indices(int64_t *idx, int64_t n, int64_t pop, uint64_t seed, uint64_t step, void *stream)
+{
+    if (!idx || n < 1 || pop < 1) return fail(BRIEF_ERR_INVALID, "bad sampler arguments");
+    hipLaunchKernelGGL(k_sample, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, idx, n, (uint64_t)pop, seed, step);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int brief_sse_u16(const uint16_t *a, const uint16_t *b, int64_t n, double *sse_out, void *stream)
+{
+    if (!a || !b || !sse_out || n < 1) return fail(BRIEF_ERR_INVALID, "bad sse arguments");
+    hipStream_t st = (hipStream_t)stream;
+    // the first 8 bytes of the output double are used as the integer accumulator, then converted in place
+    unsigned long long *acc = reinterpret_cast<unsigned long long *>(sse_out);
+    HIP_TRY(hipMemsetAsync(acc, 0, sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(k_sse_u16, dim3(1024), dim3(256), 0, st, a, b, n, acc);
+    hipLaunchKernelGGL(k_u64_to_double, dim3(1), dim3(1), 0, st, acc, sse_out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}   // extern "C"

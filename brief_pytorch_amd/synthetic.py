@@ -61,3 +61,37 @@ def make_volume(shape, seed=42, dtype=np.uint16, n_waves=8, n_blobs=32, n_tubes=
             v = np.clip(np.rint(v), info.min, info.max)
         out[z0:z1, :, :, 0] = v.astype(dtype)
     return out
+
+
+def make_volume_torch(shape, seed=42, device="cuda", n_waves=8, n_blobs=32, noise_sigma=200.0, base=16000.0, span=8000.0, slab=32):
+    """Same kind of field as make_volume, generated on the device slab by slab (512^3 in about a
+    second) for the benchmark volumes.  Returns a uint16 torch tensor (d, h, w, 1).  The field
+    parameters come from numpy's generator so they do not depend on the torch build."""
+    import torch
+    d, h, w = (int(s) for s in shape)
+    rng = np.random.default_rng(seed)
+    freqs = rng.integers(0, 7, size=(n_waves, 3)).astype(np.float32)
+    phases = rng.uniform(0, 2 * np.pi, size=n_waves).astype(np.float32)
+    amps = rng.uniform(0.3, 1.0, size=n_waves)
+    amps = (amps / amps.sum()).astype(np.float32)
+    bc = rng.uniform(0, 1, size=(n_blobs, 3)).astype(np.float32)
+    br = rng.uniform(0.03, 0.12, size=n_blobs).astype(np.float32)
+    ba = rng.uniform(0.2, 0.9, size=n_blobs).astype(np.float32)
+    out = torch.empty((d, h, w, 1), dtype=torch.uint16, device=device)
+    y = (torch.arange(h, device=device, dtype=torch.float32) / max(h - 1, 1))[None, :, None]
+    x = (torch.arange(w, device=device, dtype=torch.float32) / max(w - 1, 1))[None, None, :]
+    gen = torch.Generator(device=device)
+    for z0 in range(0, d, slab):
+        z1 = min(z0 + slab, d)
+        z = (torch.arange(z0, z1, device=device, dtype=torch.float32) / max(d - 1, 1))[:, None, None]
+        f = torch.zeros((z1 - z0, h, w), device=device)
+        for k in range(n_waves):
+            f += float(amps[k]) * torch.sin(6.283185307179586 * (float(freqs[k, 0]) * z + float(freqs[k, 1]) * y + float(freqs[k, 2]) * x) + float(phases[k]))
+        f = 0.5 + 0.35 * f
+        for k in range(n_blobs):
+            r2 = (z - float(bc[k, 0])) ** 2 + (y - float(bc[k, 1])) ** 2 + (x - float(bc[k, 2])) ** 2
+            f += float(ba[k]) * 0.25 * torch.exp(-r2 / (2 * float(br[k]) ** 2))
+        gen.manual_seed(seed * 1000003 + z0)
+        v = base + span * f + noise_sigma * torch.randn(f.shape, device=device, generator=gen)
+        out[z0:z1, :, :, 0] = v.round().clamp_(0, 65535).to(torch.int32).to(torch.uint16)
+    return out

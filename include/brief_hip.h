@@ -1,0 +1,117 @@
+/* brief_hip.h — C-ABI of libbrief_hip.so: the MI355X-native SIREN fit/decode hot path of BRIEF.
+ *
+ * The reference (RichealYoung/BRIEF_PyTorch) has no FFI for this path: it sits behind the
+ * Python object returned by init_phi() (utils/Networks.py:795-802) and the loop body in
+ * main.py:385-400.  Each entry point below names the reference code it replaces.  All pointers
+ * are DEVICE pointers (e.g. torch.Tensor.data_ptr()), `stream` is a hipStream_t passed as
+ * void*; nothing is allocated, freed or synchronised inside, so calls can be captured in a
+ * hipGraph.  Every function returns 0 on success or a negative brief_status; the message of the
+ * last failure on the calling thread is available through brief_last_error().
+ */
+#ifndef BRIEF_HIP_H
+#define BRIEF_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BRIEF_VERSION 100 /* 0.1.0 */
+
+typedef enum {
+    BRIEF_OK = 0,
+    BRIEF_ERR_INVALID = -1,      /* bad argument / unsupported configuration (e.g. res=True, F > 256) */
+    BRIEF_ERR_LAUNCH = -2,       /* HIP launch / runtime error */
+    BRIEF_ERR_WORKSPACE = -3     /* workspace too small */
+} brief_status;
+
+/* SIREN(coords_channel, data_channel, features, layers, w0, output_act)  utils/Networks.py:246-266.
+ * layers = number of Linear layers; hidden Sine() is hard-coded w0=30 in the reference (:228,259). */
+typedef struct {
+    int32_t cin;         /* 2 | 3 */
+    int32_t cout;        /* 1 .. 4 */
+    int32_t layers;      /* >= 2 */
+    int32_t features;    /* 1 .. 256 (padded to a multiple of 32 internally) */
+    float w0_first;
+    float w0_hidden;
+    int32_t output_act;
+    int32_t reserved;
+} brief_siren_desc;
+
+/* create_flattened_coords(shape, mode)  utils/dataset.py:36-60: linspace(lo,hi,n) per axis, (d,h,w) order */
+typedef struct {
+    int32_t ndim;        /* == cin */
+    int32_t reserved;
+    int64_t dims[3];
+    float lo, hi;
+} brief_grid_desc;
+
+/* where the samples of one step come from.
+ *   j = idx ? idx[n] : n + offset            (RandompointSampler main.py:154-163 / full-volume cube :112-125)
+ *   x = coords ? coords[j, :] : grid coordinate of voxel j
+ *   y = targets[j, :]      w = weights ? weights[j, :] : 1 */
+typedef struct {
+    const float *coords;     /* [*, cin] or NULL */
+    const float *targets;    /* [*, cout]  (ignored by forward) */
+    const float *weights;    /* [*, cout] or NULL */
+    const int64_t *idx;      /* [n] or NULL */
+    int64_t offset;
+    int64_t n;               /* samples in this call */
+} brief_batch_desc;
+
+typedef enum { BRIEF_LOSS_L2 = 0, BRIEF_LOSS_SMOOTHL1 = 1 } brief_loss_kind;      /* main.py:176-191 */
+typedef enum { BRIEF_OPT_ADAMAX = 0, BRIEF_OPT_ADAM = 1, BRIEF_OPT_SGD = 2 } brief_optim_kind; /* utils/misc.py:174-183 */
+typedef enum { BRIEF_OUT_F32 = 0, BRIEF_OUT_U8 = 1, BRIEF_OUT_U16 = 2 } brief_out_kind;
+
+int brief_version(void);
+const char *brief_last_error(void);
+
+/* number of floats in the canonical packed parameter buffer (W0,b0,W1,b1,... == torch parameters()
+ * order; W_l row-major [out,in] as in utils/ModelSave.py:32-50).  == SIREN.calc_param_count */
+int64_t brief_param_count(const brief_siren_desc *d);
+/* floats in the derived MFMA-fragment-ordered weight buffer produced by brief_siren_repack */
+int64_t brief_packed_count(const brief_siren_desc *d);
+/* bytes of scratch a train step of n samples needs (activation stash + gradient slabs) */
+int64_t brief_train_workspace_bytes(const brief_siren_desc *d, int64_t n);
+
+/* canonical params -> fragment-ordered copies read by the kernels.  Call after every change of
+ * `params` made outside brief_optim_step's caller loop (init, load_model utils/ModelSave.py:8-27). */
+int brief_siren_repack(const brief_siren_desc *d, const float *params, float *packed, void *stream);
+
+/* SIREN.forward under no_grad (main.py:266-268 sample_nf; utils/misc.py:59-92 reconstruct_flattened).
+ * out_kind F32: out = yhat [n,cout] float.  U8/U16: fused invnormalize_data('minmaxany_a_b')
+ * (utils/io.py:136-147): clip((yhat-a)/(b-a),0,1)*(vmax-vmin)+vmin truncated to the integer type. */
+int brief_siren_forward(const brief_siren_desc *d, const float *packed, const brief_grid_desc *grid,
+                        const brief_batch_desc *batch, void *out, int out_kind,
+                        float scale_min, float scale_max, double vmin, double vmax, void *stream);
+
+/* zero_grad + forward + loss + backward of main.py:385-396 for one batch.
+ * grads: canonical packed layout, fully overwritten.  loss_out: one float (mean loss).
+ * yhat_out: optional [n,cout].  thr: normalised weight_thres (0 disables, main.py:178-179). */
+int brief_siren_train_step(const brief_siren_desc *d, const float *packed, const brief_grid_desc *grid,
+                           const brief_batch_desc *batch, int loss_kind, float thr, float beta,
+                           float *grads, float *loss_out, float *yhat_out,
+                           void *workspace, int64_t workspace_bytes, void *stream);
+
+/* optimizer.step() of main.py:399 (torch.optim.Adamax/Adam/SGD single-tensor rules); t is the
+ * 1-based step count, lr the scheduler's current value.  state1/state2: exp_avg / exp_inf|exp_avg_sq. */
+int brief_optim_step(int kind, float *params, const float *grads, float *state1, float *state2, int64_t count,
+                     double lr, double beta1, double beta2, double eps, int64_t t, void *stream);
+
+/* uniform voxel indices in [0, pop) for one step: the device-side stand-in for
+ * torch.randint(0, pop_size, (n,)) of main.py:156 (counter-based Philox4x32-10, keyed by seed/step). */
+int brief_sample_indices(int64_t *idx, int64_t n, int64_t pop, uint64_t seed, uint64_t step, void *stream);
+
+/* sum of squared differences of two integer volumes (for PSNR, utils/misc.py:451-456); sse_out: one double */
+int brief_sse_u16(const uint16_t *a, const uint16_t *b, int64_t n, double *sse_out, void *stream);
+
+/* measurement hooks (bench.py): while enabled, every train step records a HIP event pair on the
+ * caller's stream around its dominant kernel (the fused forward/loss/dgrad launch);
+ * brief_profile_fused waits for them and returns the summed duration and the launch count. */
+int brief_profile_enable(int on);
+int brief_profile_fused(double *total_ms, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

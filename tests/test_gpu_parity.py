@@ -1,0 +1,260 @@
+"""GPU parity tests proper: the HIP path (through the C-ABI) against the CPU oracle on the same
+seeded inputs and against the golden vectors produced by the reference.
+
+Tolerances (fp32 path): forward <= 2e-5 of max|y|, every gradient tensor
+<= 1e-4 of its max-abs, loss <= 1e-5 relative, 50-step loss trace <= 1e-4 relative,
+optimizer update bit-exact, integer outputs bit-exact given identical yhat.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from brief_pytorch_amd import _lib
+from brief_pytorch_amd.networks import SIREN
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-30))
+
+
+def make_net(L, F, w0, cin=3, cout=1, oa=False, seed=0, ws=None, bs=None):
+    torch.manual_seed(seed)
+    m = SIREN(coords_channel=cin, data_channel=cout, features=F, layers=L, w0=w0, output_act=oa)
+    if ws is not None:
+        for l in range(L):
+            m.net[l][0].weight.data = torch.from_numpy(ws[l])
+            m.net[l][0].bias.data = torch.from_numpy(bs[l])
+    d = O.make_desc(cin, cout, L, F, w0, 30.0, oa)
+    p = m.params.numpy().copy()
+    return m.to(DEV), d, p
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e", "f"])
+def test_forward_golden(golden, tag):
+    g = golden("forward")
+    L, F, w0, cin, cout, oa = [int(v) for v in g[tag + "_cfg"]]
+    if tag + "_w0" in g:
+        m, d, p = make_net(L, F, w0, cin, cout, bool(oa), ws=[g["%s_w%d" % (tag, l)] for l in range(L)],
+                           bs=[g["%s_b%d" % (tag, l)] for l in range(L)])
+    else:
+        m, d, p = make_net(L, F, w0, cin, cout, bool(oa), seed=int(g[tag + "_seed"][0]))
+    y = m.forward(torch.from_numpy(g[tag + "_x"]).to(DEV)).cpu().numpy()
+    assert relerr(y, g[tag + "_y"]) < 2e-5                      # vs the reference itself
+    assert relerr(y, O.forward(d, p, g[tag + "_x"])) < 2e-5     # vs the oracle
+
+
+@pytest.mark.parametrize("L,F,cin,cout,n", [(2, 16, 3, 1, 100), (3, 33, 3, 1, 31), (4, 96, 2, 3, 1000), (5, 130, 3, 1, 257),
+                                             (6, 200, 3, 1, 65), (3, 224, 3, 3, 1), (5, 256, 3, 1, 4097), (9, 64, 3, 1, 513)])
+def test_forward_shapes_vs_oracle(L, F, cin, cout, n):
+    m, d, p = make_net(L, F, 20.0, cin, cout, seed=L * 100 + F)
+    x = np.random.default_rng(F).uniform(-1, 1, size=(n, cin)).astype(np.float32)
+    y = m.forward(torch.from_numpy(x).to(DEV)).cpu().numpy()
+    assert y.shape == (n, cout)
+    assert relerr(y, O.forward(d, p, x)) < 2e-5
+
+
+def _check_grads(m, d, grads_ref, tol=1e-4):
+    gw, gb = O.unpack_params(d, grads_ref)
+    mw, mb = O.unpack_params(d, m.grads.cpu().numpy())
+    for l in range(d.layers):
+        assert relerr(mw[l], gw[l]) < tol, ("weight", l)
+        assert relerr(mb[l], gb[l]) < tol, ("bias", l)
+
+
+@pytest.mark.parametrize("tag", ["mse_unit", "mse_unit_thr", "mse_w_thr", "sl1_w", "mse_256"])
+def test_loss_grads_golden(golden, tag):
+    g = golden("grads")
+    L, F, w0, kind, thr, beta = g[tag + "_cfg"]
+    L, F, kind = int(L), int(F), int(kind)
+    if tag + "_w0" in g:
+        m, d, p = make_net(L, F, w0, ws=[g["%s_w%d" % (tag, l)] for l in range(L)], bs=[g["%s_b%d" % (tag, l)] for l in range(L)])
+    else:
+        m, d, p = make_net(L, F, w0, seed=3)
+    x, y, w = (torch.from_numpy(g[tag + k]).to(DEV) for k in ("_x", "_y", "_w"))
+    loss, yhat = m.train_step(x.shape[0], y, coords=x, weights=w, loss=["datal2", "datasmoothl1"][kind], thr=float(thr),
+                              beta=float(beta), want_yhat=True)
+    assert abs(loss.item() - g[tag + "_loss"][0]) / abs(g[tag + "_loss"][0]) < 1e-5
+    assert relerr(yhat.cpu().numpy(), g[tag + "_yhat"]) < 2e-5
+    lo, go, _, _ = O.loss_grad(d, p, g[tag + "_x"], g[tag + "_y"], g[tag + "_w"], kind, float(thr), float(beta))
+    assert abs(loss.item() - lo) / abs(lo) < 1e-5
+    _check_grads(m, d, go)
+    if tag + "_gw0" in g and tag + "_w0" in g:      # reference's own gradients
+        mw, mb = O.unpack_params(d, m.grads.cpu().numpy())
+        for l in range(L):
+            assert relerr(mw[l], g["%s_gw%d" % (tag, l)]) < 1e-4
+            assert relerr(mb[l], g["%s_gb%d" % (tag, l)]) < 1e-4
+    if tag == "mse_256":
+        mw, mb = O.unpack_params(d, m.grads.cpu().numpy())
+        assert relerr(mw[2][5], g["mse_256_gw2_row5"]) < 1e-4
+        assert relerr(mb[1], g["mse_256_gb1"]) < 1e-4
+        assert relerr(mw[0], g["mse_256_gw0"]) < 1e-4
+        assert relerr(mw[4], g["mse_256_gw4"]) < 1e-4
+
+
+@pytest.mark.parametrize("L,F,cin,cout,n,oa", [(2, 16, 3, 1, 100, False), (3, 33, 3, 1, 31, False), (4, 96, 2, 3, 1000, False),
+                                                (5, 130, 3, 1, 2500, False), (6, 200, 3, 1, 650, False), (3, 224, 3, 3, 1, False),
+                                                (5, 256, 3, 1, 9000, False), (9, 64, 3, 1, 513, False), (4, 48, 3, 1, 777, True)])
+def test_train_step_shapes_vs_oracle(L, F, cin, cout, n, oa):
+    m, d, p = make_net(L, F, 20.0, cin, cout, oa, seed=L * 10 + F)
+    rng = np.random.default_rng(F + n)
+    x = rng.uniform(-1, 1, size=(n, cin)).astype(np.float32)
+    y = rng.uniform(0, 100, size=(n, cout)).astype(np.float32)
+    w = np.where(rng.uniform(size=(n, cout)) < 0.5, 0.25, 1.0).astype(np.float32)
+    loss, _ = m.train_step(n, torch.from_numpy(y).to(DEV), coords=torch.from_numpy(x).to(DEV),
+                           weights=torch.from_numpy(w).to(DEV), thr=30.0)
+    lo, go, _, _ = O.loss_grad(d, p, x, y, w, 0, 30.0, 0.01)
+    assert abs(loss.item() - lo) / abs(lo) < 1e-5
+    _check_grads(m, d, go)
+
+
+def test_train_step_is_deterministic_and_batch_split_linear():
+    """Property tests at a larger size: two launches give identical bits (no atomics), and the
+    gradient of a batch is the count-weighted sum of the gradients of its two halves."""
+    m, d, p = make_net(5, 256, 20.0, seed=5)
+    n = 20000
+    rng = np.random.default_rng(1)
+    x = torch.from_numpy(rng.uniform(-1, 1, size=(n, 3)).astype(np.float32)).to(DEV)
+    y = torch.from_numpy(rng.uniform(0, 100, size=(n, 1)).astype(np.float32)).to(DEV)
+    l1, _ = m.train_step(n, y, coords=x)
+    g1 = m.grads.clone()
+    l2, _ = m.train_step(n, y, coords=x)
+    assert torch.equal(g1, m.grads) and l1.item() == l2.item()
+    h = 12000
+    m.train_step(h, y[:h].contiguous(), coords=x[:h].contiguous())
+    ga = m.grads.clone().double()
+    m.train_step(n - h, y[h:].contiguous(), coords=x[h:].contiguous())
+    gb = m.grads.clone().double()
+    comb = (ga * h + gb * (n - h)) / n
+    assert relerr(comb.cpu().numpy(), g1.double().cpu().numpy()) < 2e-5
+
+
+@pytest.mark.parametrize("name", ["Adamax", "Adam", "SGD"])
+def test_optim_step_bit_exact_vs_oracle(name):
+    rng = np.random.default_rng(11)
+    n = 100003
+    p = rng.normal(size=n).astype(np.float32)
+    s1, s2 = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    tp, ts1, ts2 = (torch.from_numpy(a.copy()).to(DEV) for a in (p, s1, s2))
+    for t in range(1, 6):
+        g = (rng.normal(size=n) * 10 ** rng.uniform(-6, 2, size=n)).astype(np.float32)
+        lr = 1e-3 * 0.2 ** (t // 3)
+        O.optim_step(name, p, g, s1, s2, lr, t)
+        tg = torch.from_numpy(g).to(DEV)
+        _lib.check(_lib.lib().brief_optim_step(_lib.OPT_KIND[name], _lib.ptr(tp), _lib.ptr(tg), _lib.ptr(ts1), _lib.ptr(ts2), n,
+                                               lr, 0.9, 0.999, 1e-8, t, _lib.stream_ptr()))
+        assert np.array_equal(tp.cpu().numpy(), p), t
+        assert np.array_equal(ts1.cpu().numpy(), s1) and np.array_equal(ts2.cpu().numpy(), s2)
+
+
+def _fit_gpu(m, steps, vn, dims, idx_stream, thr, lr=1e-3):
+    n_pop = int(np.prod(dims))
+    tv = torch.from_numpy(vn.reshape(-1, 1)).to(DEV)
+    s1, s2 = torch.zeros_like(m.params), torch.zeros_like(m.params)
+    losses = []
+    for t in range(1, steps + 1):
+        if idx_stream is None:
+            loss, _ = m.train_step(n_pop, tv, grid=(dims, -1.0, 1.0), thr=thr)
+        else:
+            idx = torch.from_numpy(idx_stream[t - 1]).to(DEV)
+            loss, _ = m.train_step(idx.numel(), tv, idx=idx, grid=(dims, -1.0, 1.0), thr=thr)
+        _lib.check(_lib.lib().brief_optim_step(0, _lib.ptr(m.params), _lib.ptr(m.grads), _lib.ptr(s1), _lib.ptr(s2), m.params.numel(),
+                                               lr, 0.9, 0.999, 1e-8, t, _lib.stream_ptr()))
+        m._stale = True
+        losses.append(loss.item())
+    return np.array(losses)
+
+
+def test_trace_full_batch_golden(golden):
+    g = golden("trace")
+    m, d, p = make_net(5, 22, 20.0, ws=[g["cube_init_w%d" % l] for l in range(5)], bs=[g["cube_init_b%d" % l] for l in range(5)])
+    vol = g["cube_vol"]
+    vn, _ = O.normalize(vol)
+    losses = _fit_gpu(m, 50, vn, vol.shape[:3], None, float(g["cube_thr"][0]))
+    assert np.max(np.abs(losses - g["cube_losses"]) / g["cube_losses"]) < 1e-4
+    for l in range(5):
+        assert np.max(np.abs(m.net[l][0].weight.data.cpu().numpy() - g["cube_final_w%d" % l])) < 5e-5
+
+
+def test_trace_randompoint_golden(golden):
+    g = golden("trace")
+    m, d, p = make_net(4, 32, 20.0, ws=[g["pt_init_w%d" % l] for l in range(4)], bs=[g["pt_init_b%d" % l] for l in range(4)])
+    vol = g["pt_vol"]
+    vn, side = O.normalize(vol)
+    thr = float(O.normalize(np.array([65535], np.uint16), vmin=side["min"], vmax=side["max"])[0][0])
+    losses = _fit_gpu(m, 50, vn, vol.shape[:3], g["pt_idx"], thr)
+    assert np.max(np.abs(losses - g["pt_losses"]) / g["pt_losses"]) < 1e-4
+    for l in range(4):
+        assert np.max(np.abs(m.net[l][0].weight.data.cpu().numpy() - g["pt_final_w%d" % l])) < 5e-5
+
+
+def test_decode_golden(golden):
+    g = golden("decode")
+    vol = g["vol"]
+    m, d, p = make_net(5, 22, 20.0, ws=[g["net_w%d" % l] for l in range(5)], bs=[g["net_b%d" % l] for l in range(5)])
+    dims = vol.shape[:3]
+    dec = m.decode_grid(dims).cpu().numpy().reshape(vol.shape)
+    assert relerr(dec, g["dec_f32"]) < 2e-5
+    _, side = O.normalize(vol)
+    u16 = m.decode_grid(dims, out_kind="u16", scale=(0.0, 100.0), vrange=(side["min"], side["max"])).cpu().numpy().reshape(vol.shape)
+    # fused epilogue == oracle epilogue applied to the kernel's own yhat, bit for bit
+    assert np.array_equal(u16, O.invnormalize(dec, side))
+    diff = np.abs(u16.astype(np.int64) - g["dec_u16"].astype(np.int64))
+    assert diff.max() <= 1 and (diff != 0).mean() < 0.02
+    assert abs(O.psnr(vol, u16, 65535) - g["psnr"][0]) < 0.01
+    # chunked / offset decode gives the same voxels
+    part = m.decode_grid(dims, offset=1000, count=777).cpu().numpy()
+    assert np.array_equal(part.ravel(), dec.ravel()[1000:1777])
+    # in-kernel coordinate synthesis == explicit coords from the oracle's linspace restatement
+    xy = torch.from_numpy(O.grid_coords(dims)).to(DEV)
+    assert np.array_equal(m.forward(xy).cpu().numpy().ravel(), dec.ravel())
+
+
+def test_decode_2d_u8():
+    m, d, p = make_net(4, 40, 20.0, cin=2, cout=3, seed=9)
+    dims = (37, 53)
+    dec = m.decode_grid(dims).cpu().numpy()
+    ref = O.forward(d, p, O.grid_coords(dims))
+    assert relerr(dec, ref) < 2e-5
+    side = {"dtype": "uint8", "min": 3.0, "max": 250.0}
+    u8 = m.decode_grid(dims, out_kind="u8", scale=(0.0, 100.0), vrange=(3.0, 250.0)).cpu().numpy()
+    assert np.array_equal(u8, O.invnormalize(dec * 400.0 / 400.0, side))
+
+
+def test_sample_indices_and_sse():
+    n, pop = 200000, 512 ** 3
+    a = torch.empty(n, dtype=torch.int64, device=DEV)
+    b = torch.empty(n, dtype=torch.int64, device=DEV)
+    L = _lib.lib()
+    _lib.check(L.brief_sample_indices(_lib.ptr(a), n, pop, 42, 7, _lib.stream_ptr()))
+    _lib.check(L.brief_sample_indices(_lib.ptr(b), n, pop, 42, 7, _lib.stream_ptr()))
+    assert torch.equal(a, b)
+    _lib.check(L.brief_sample_indices(_lib.ptr(b), n, pop, 42, 8, _lib.stream_ptr()))
+    assert not torch.equal(a, b)
+    an = a.cpu().numpy()
+    assert an.min() >= 0 and an.max() < pop
+    assert abs(an.mean() / pop - 0.5) < 0.01 and len(np.unique(an)) > 0.99 * n
+    hist = np.histogram(an, bins=16, range=(0, pop))[0]
+    assert hist.min() > 0.9 * n / 16
+    rng = np.random.default_rng(0)
+    u = rng.integers(0, 65536, size=1 << 20).astype(np.uint16)
+    v = rng.integers(0, 65536, size=1 << 20).astype(np.uint16)
+    out = torch.zeros(1, dtype=torch.float64, device=DEV)
+    tu, tv = torch.from_numpy(u).to(DEV), torch.from_numpy(v).to(DEV)
+    _lib.check(L.brief_sse_u16(_lib.ptr(tu), _lib.ptr(tv), u.size, _lib.ptr(out), _lib.stream_ptr()))
+    assert out.item() == float(((u.astype(np.int64) - v.astype(np.int64)) ** 2).sum())
+
+
+def test_errors_are_loud():
+    L = _lib.lib()
+    d = _lib.SirenDesc(3, 1, 5, 300, 20.0, 30.0, 0, 0)
+    assert L.brief_packed_count(C.byref(d)) == -1
+    m, _, _ = make_net(3, 16, 20.0)
+    with pytest.raises(_lib.BriefError):
+        m.train_step(10, torch.zeros(10, 1, device=DEV), coords=None, grid=((4, 4), -1.0, 1.0))   # ndim != cin

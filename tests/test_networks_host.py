@@ -1,0 +1,76 @@
+"""Host-side pieces of the SIREN drop-in against goldens from the reference (CPU only)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from brief_pytorch_amd import _lib
+from brief_pytorch_amd.networks import SIREN, get_nnmodule_param_count, init_phi
+
+
+@pytest.mark.parametrize("seed", [0, 42])
+@pytest.mark.parametrize("LF", [(3, 64), (5, 22), (7, 56)])
+def test_init_replays_reference_rng(golden, seed, LF):
+    g = golden("init")
+    L, F = LF
+    torch.manual_seed(seed)
+    m = SIREN(coords_channel=3, data_channel=1, features=F, layers=L, w0=20)
+    for l in range(L):
+        assert np.array_equal(m.net[l][0].weight.data.numpy(), g["s%d_L%d_F%d_w%d" % (seed, L, F, l)])
+        assert np.array_equal(m.net[l][0].bias.data.numpy(), g["s%d_L%d_F%d_b%d" % (seed, L, F, l)])
+
+
+@pytest.mark.parametrize("seed", [0, 42])
+def test_init_256(golden, seed):
+    g = golden("init")
+    torch.manual_seed(seed)
+    m = SIREN(features=256, layers=5, w0=20)
+    sd = {("w%d" % l): m.net[l][0].weight.data.numpy() for l in range(5)}
+    sd.update({("b%d" % l): m.net[l][0].bias.data.numpy() for l in range(5)})
+    sums = np.array([sd[k].astype(np.float64).sum() for k in sorted(sd)])
+    assert np.array_equal(sums, g["s%d_L5_F256_sums" % seed])
+    assert np.array_equal(sd["w1"][0], g["s%d_L5_F256_w1_row0" % seed])
+    assert np.array_equal(sd["b3"], g["s%d_L5_F256_b3" % seed])
+
+
+def test_budget_table(golden):
+    g = golden("budget")
+    for L, cin, cout, nbytes, F, P in g["table"]:
+        f = SIREN.calc_features(nbytes / 4.0, int(cin), int(cout), int(L), False)
+        assert f == int(F)
+        assert SIREN.calc_param_count(int(cin), int(cout), f, int(L), False) == int(P)
+
+
+def test_module_surface():
+    torch.manual_seed(1)
+    m = init_phi({"name": "SIREN", "coords_channel": 3, "data_channel": 1, "layers": 5, "w0": 20,
+                  "output_act": False, "res": False, "features": 22})
+    assert get_nnmodule_param_count(m) == SIREN.calc_param_count(3, 1, 22, 5) == m.params.numel()
+    assert len(m.net) == 5 and m.net[1][0].weight.shape == (22, 22)
+    w = torch.arange(22 * 22, dtype=torch.float32).reshape(22, 22)
+    m.net[2][0].weight.data = w                      # utils/ModelSave.py:20 style assignment
+    assert torch.equal(m.net[2][0].weight.data, w) and m._stale
+    assert torch.equal(m.state_dict()["net.2.0.weight"], w)
+    with pytest.raises(NotImplementedError):
+        init_phi({"name": "NeRF"})
+    with pytest.raises(NotImplementedError):
+        SIREN(res=True)
+    with pytest.raises(_lib.BriefError):           # no CPU fallback
+        m.forward(torch.zeros(4, 3))
+
+
+def test_capi_exports_and_sizes():
+    import os
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libbrief_hip.so not built")
+    L = _lib.lib()
+    for name in _lib.EXPORTS:
+        assert hasattr(L, name), name
+    assert L.brief_version() == 100
+    d = _lib.SirenDesc(3, 1, 5, 256, 20.0, 30.0, 0, 0)
+    assert L.brief_param_count(C.byref(d)) == 198657
+    assert L.brief_packed_count(C.byref(d)) == 256 * 4 + 3 * (2 * 256 * 256 + 256) + 4 * 256 + 4
+    assert L.brief_train_workspace_bytes(C.byref(d), 100000) > 6 * 256 * 100000 * 4
+    bad = _lib.SirenDesc(3, 1, 5, 512, 20.0, 30.0, 0, 0)
+    assert L.brief_param_count(C.byref(bad)) == -1 and b"features" in L.brief_last_error()
