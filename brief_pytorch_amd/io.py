@@ -1,0 +1,135 @@
+"""Normalise / de-normalise and small file helpers (reference utils/io.py:65-214, 216-313).
+
+normalize_data / invnormalize_data reproduce the reference's float32 operation order exactly
+(tests pin them bit for bit against golden vectors).  On the fused path the de-normalise step is
+normally done inside the decode kernel (SIREN.decode_grid(out_kind='u16')); the numpy versions
+here serve host-side callers and the checker of that epilogue.
+"""
+import os
+
+import numpy as np
+import torch
+import yaml
+
+_TYPE_MAX = {"uint8": 255, "uint12": 4098, "uint16": 65535, "float32": 65535, "float64": 65535, "int16": 65535}
+
+
+def get_type_max(data):
+    """utils/tool.py:8-24"""
+    name = data.dtype.name if hasattr(data.dtype, "name") else str(data.dtype).replace("torch.", "")
+    if name not in _TYPE_MAX:
+        raise NotImplementedError(name)
+    return _TYPE_MAX[name]
+
+
+def range_limit(data, rng):
+    """utils/tool.py:26-30"""
+    l, h = rng
+    assert l >= 0 and l <= h and h <= get_type_max(data), "Improper range setting!"
+    return [l, h]
+
+
+def normalize_data(data, name, min=None, max=None):
+    """utils/io.py:65-112 -> (torch.float32 tensor, sideinfos)"""
+    if "minmaxany" in name:
+        scale_min, scale_max = (float(v) for v in name.split("_")[1:])
+        dtype = data.dtype.name
+        data = data.astype(np.float32)
+        if min is None:
+            min = float(data.min())
+        if max is None:
+            max = float(data.max())
+        data = (data - min) / (max - min)
+        data *= (scale_max - scale_min)
+        data += scale_min
+        data = torch.tensor(data, dtype=torch.float)
+        return data, {"dtype": dtype, "min": min, "max": max, "normalized_min": data.min().item(), "normalized_max": data.max().item()}
+    if name == "minmax01_0mean":
+        dtype = data.dtype.name
+        data = data.astype(np.float32)
+        min, max = float(data.min()), float(data.max())
+        data = (data - min) / (max - min)
+        mean = data.mean()
+        data = torch.tensor(data - mean, dtype=torch.float)
+        return data, {"dtype": dtype, "min": min, "max": max, "mean": mean, "normalized_min": -mean, "normalized_max": 1 - mean}
+    if name == "minmax01_0mean1std":
+        dtype = data.dtype.name
+        data = data.astype(np.float32)
+        min, max = float(data.min()), float(data.max())
+        data = (data - min) / (max - min)
+        mean, std = data.mean(), data.std()
+        data = torch.tensor((data - mean) / std, dtype=torch.float)
+        return data, {"dtype": dtype, "min": min, "max": max, "mean": mean, "std": std,
+                      "normalized_min": (-mean) / std, "normalized_max": (1 - mean) / std}
+    if name == "none":
+        dtype = data.dtype.name
+        data = data.astype(np.float32)
+        min, max = float(data.min()), float(data.max())
+        return torch.tensor(data, dtype=torch.float), {"dtype": dtype, "min": min, "max": max, "normalized_min": min, "normalized_max": max}
+    raise NotImplementedError(name)
+
+
+def invnormalize_data(data, sideinfos, name):
+    """utils/io.py:114-214 (data: torch tensor, modified in place like the reference)"""
+    dtype = sideinfos["dtype"]
+    if dtype not in ("uint8", "uint16", "float32", "float64", "int16"):
+        raise NotImplementedError(dtype)
+    min, max = sideinfos["min"], sideinfos["max"]
+    if "minmaxany" in name:
+        scale_min, scale_max = (float(v) for v in name.split("_")[1:])
+        data -= scale_min
+        data /= (scale_max - scale_min)
+        data = torch.clip(data, 0, 1)
+        data = data * (max - min) + min
+    elif name == "minmax01":
+        data = torch.clip(data, 0, 1) * (max - min) + min
+    elif name == "minmaxn11":
+        data = (torch.clip(data, -1, 1) / 2 + 0.5) * (max - min) + min
+    elif name == "minmax01_0mean":
+        data = torch.clip(data + sideinfos["mean"], 0, 1) * (max - min) + min
+    elif name == "minmax01_0mean1std":
+        data = torch.clip(data * sideinfos["std"] + sideinfos["mean"], 0, 1) * (max - min) + min
+    elif name == "none":
+        data = torch.clip(data, min, max)
+    else:
+        raise NotImplementedError(name)
+    return data.numpy().astype(dtype)      # truncating cast, as np.array(tensor, dtype=...) does
+
+
+def minmaxany_range(name):
+    """(a, b) of 'minmaxany_a_b', the only normalisation the fused decode epilogue implements"""
+    if "minmaxany" not in name:
+        return None
+    a, b = (float(v) for v in name.split("_")[1:])
+    return a, b
+
+
+def get_folder_size(folder_path):
+    """utils/io.py get_folder_size: bytes of every file below the folder"""
+    total = 0
+    for root, _, files in os.walk(folder_path):
+        for f in files:
+            total += os.path.getsize(os.path.join(root, f))
+    return total
+
+
+def _plain(o):
+    if isinstance(o, dict):
+        return {str(k): _plain(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_plain(v) for v in o]
+    if isinstance(o, (np.floating,)):
+        return float(o)
+    if isinstance(o, (np.integer,)):
+        return int(o)
+    return o
+
+
+def save_yaml(obj, path):
+    with open(path, "w") as f:
+        yaml.safe_dump(_plain(obj), f, sort_keys=False)
+
+
+def load_yaml(path):
+    with open(path) as f:
+        return yaml.safe_load(f)

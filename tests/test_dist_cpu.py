@@ -1,0 +1,68 @@
+"""N>1 path on CPU: two gloo ranks shard the blocks of a volume, each scores only its own blocks,
+the all-reduced [SSE, n] must give the same PSNR as one process scoring everything."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+from brief_pytorch_amd.dist_utils import allreduce_sse, assign_blocks
+from brief_pytorch_amd.metrics import psnr_from_sse
+from brief_pytorch_amd.misc import divide_data
+from brief_pytorch_amd.synthetic import make_volume
+
+
+def test_assign_blocks_lpt():
+    costs = [8, 7, 6, 5, 4, 3, 2, 1]
+    own = assign_blocks(costs, 2)
+    loads = [sum(c for c, o in zip(costs, own) if o == r) for r in range(2)]
+    assert sorted(own.count(r) for r in range(2)) == [4, 4] and abs(loads[0] - loads[1]) <= 1
+    assert assign_blocks([1.0] * 8, 8) == list(range(8))            # C4: eight equal octants -> one per GPU
+    assert assign_blocks(costs, 1) == [0] * 8
+    mixed = [64, 16, 16, 16, 16, 4, 4, 4, 4, 4, 4, 4, 4]              # C5-like mixed block sizes
+    own = assign_blocks(mixed, 4)
+    loads = [sum(c for c, o in zip(mixed, own) if o == r) for r in range(4)]
+    assert max(loads) == 64 and min(loads) >= 32
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    vol = make_volume((12, 16, 20), seed=5)
+    rng = np.random.default_rng(0)
+    dec = np.clip(vol.astype(np.int64) + rng.integers(-50, 50, size=vol.shape), 0, 65535).astype(np.uint16)
+    chunks, _ = divide_data(vol, "total_2_2_2")
+    dchunks, _ = divide_data(dec, "total_2_2_2")
+    own = assign_blocks([float(c["size"]) for c in chunks], world)
+    sse, cnt = 0.0, 0.0
+    for i, (c, dc) in enumerate(zip(chunks, dchunks)):
+        if own[i] == rank:
+            d = c["data"].astype(np.int64) - dc["data"].astype(np.int64)
+            sse += float((d * d).sum())
+            cnt += float(c["size"])
+    tot, n = allreduce_sse([sse], cnt, "cpu")
+    full = vol.astype(np.int64) - dec.astype(np.int64)
+    q.put((rank, float(tot[0]), n, float((full * full).sum()), float(vol.size), cnt))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sse_allreduce():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, tot, n, full, size, own_cnt in res:
+        assert tot == full and n == size and 0 < own_cnt < size
+        assert abs(psnr_from_sse(tot, n, 65535) - psnr_from_sse(full, size, 65535)) == 0

@@ -1,0 +1,92 @@
+"""End-to-end on the GPU through the reference-shaped framework API: SingleTask fit ->
+artefact tree -> decode from the files -> metrics, against the reference's own 300-step run
+(golden decode.npz) with the end-of-fit band of SURVEY.md Appendix F (|dPSNR| <= 0.1 dB), and
+DivideTask on one rank."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from brief_pytorch_amd import config, misc
+from brief_pytorch_amd.framework import NFGR, MyLogger
+from brief_pytorch_amd.networks import SIREN
+from brief_pytorch_amd.tool import read_img, save_img
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _opt(tmp_path, steps, ckpt, given):
+    opt = config.load(os.path.join(ROOT, "opt", "SingleTask", "default.yaml"))
+    cf = opt.CompressFramework
+    cf.Compress.max_steps = steps
+    cf.Compress.checkpoints = ckpt
+    cf.Compress.param.filesize_ratio = 0
+    cf.Compress.param.given_size = given
+    cf.Compress.loss_log_freq = 50
+    opt.Log.outputs_dir = str(tmp_path / "outputs")
+    opt.Log.time = False
+    return opt
+
+
+def test_singletask_matches_reference_run(tmp_path, golden):
+    g = golden("decode")
+    vol = g["vol"]
+    path = str(tmp_path / "vol.tif")
+    save_img(path, vol)
+    assert np.array_equal(read_img(path), vol)
+    opt = _opt(tmp_path, 300, "every_100", 4.0 * SIREN.calc_param_count(3, 1, 22, 5))
+    Log = MyLogger(**opt.Log)
+    torch.manual_seed(42)                                   # reproduc(seed 42), as in the golden run
+    fw = NFGR(opt.CompressFramework, Log=Log)
+    res = fw.compress(path)
+    assert sorted(res) == [100, 200, 300]
+    assert abs(res[300]["psnr"] - g["psnr"][0]) < 0.1          # reference: same init, same batches
+    assert abs(res[300]["ssim"] - g["ssim"][0]) < 5e-3
+    assert abs(res[300]["loss"] - g["losses"][-1]) / g["losses"][-1] < 5e-3
+    # artefact tree
+    sdir = os.path.join(Log.logdir, "steps300")
+    mod = os.path.join(sdir, "compressed", "module")
+    assert sorted(os.listdir(mod)) == sorted(["weight-0-22-3", "bias-0-22", "weight-1-22-22", "bias-1-22", "weight-2-22-22",
+                                              "bias-2-22", "weight-3-22-22", "bias-3-22", "weight-4-1-22", "bias-4-1"])
+    side = config.load(os.path.join(sdir, "compressed", "sideinfos.yaml"))
+    assert set(side) == {"dtype", "min", "max", "normalized_min", "normalized_max", "data_shape", "phi_features", "phi_name"}
+    assert side["phi_features"] == 22 and list(side["data_shape"]) == list(vol.shape)
+    dec_file = read_img(os.path.join(sdir, "decompressed", "vol_decompressed.tif"))
+    # decoding the stored artefact again reproduces the stored volume bit for bit
+    again = NFGR.decompress(config.to_opt({"CompressFramework": opt.CompressFramework}), mod, dict(side))
+    assert np.array_equal(again, dec_file)
+    assert os.path.exists(os.path.join(Log.logdir, "performance.csv"))
+    assert os.path.exists(os.path.join(sdir, "mip", "vol_mip_d.tif"))
+    # the reference's final weights decode to (almost) the same volume as ours: same basin
+    d = np.abs(dec_file.astype(np.int64) - g["dec_u16"].astype(np.int64))
+    assert np.median(d) < 40
+
+
+def test_dividetask_single_rank(tmp_path):
+    from brief_pytorch_amd.synthetic import make_volume
+    vol = make_volume((16, 32, 32), seed=3)
+    path = str(tmp_path / "blk.tif")
+    save_img(path, vol)
+    opt = _opt(tmp_path, 200, "none", 20000.0)
+    cf = opt.CompressFramework
+    cf.Compress.divide.divide_type = "total_1_2_2"
+    cf.Compress.divide.param_alloc = "by_size"
+    cf.Module.phi.layers = 4
+    Log = MyLogger(**opt.Log)
+    torch.manual_seed(42)
+    fw = NFGR(cf, Log=Log)
+    res = fw.compress_divide(path, opt)
+    assert list(res) == [200] and res[200]["psnr"] > 24     # 200 steps only: a sanity floor, not a quality claim
+    cdir = os.path.join(Log.logdir, "steps200", "compressed")
+    names = sorted(os.listdir(os.path.join(cdir, "module")))
+    assert names == sorted(c["name"] for c in misc.divide_data(vol, "total_1_2_2")[0])
+    top = config.load(os.path.join(cdir, "sideinfos.yaml"))
+    assert top["chunks_numbers"] == 4 and list(top["data_shape"]) == list(vol.shape)
+    for n in names:
+        assert os.path.exists(os.path.join(cdir, "module", n, "module", "bias-0-%d" % config.load(os.path.join(cdir, "sideinfos", n, "sideinfos.yaml"))["phi_features"]))
+    merged = read_img(os.path.join(Log.logdir, "steps200", "decompressed", "blk_decompressed.tif"))
+    d = merged.astype(np.float64) - vol.astype(np.float64)
+    assert abs(-10 * np.log10((d * d).mean() / 65535.0 ** 2) - res[200]["psnr"]) < 1e-6

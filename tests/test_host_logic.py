@@ -1,0 +1,102 @@
+"""Host-side mirror of the reference interface (normalise, weight files, metrics, schedules,
+partition/budget/merge) against golden vectors produced by running the reference.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from brief_pytorch_amd import io as bio
+from brief_pytorch_amd import metrics, misc, modelsave
+from brief_pytorch_amd.networks import SIREN
+
+
+def test_normalize_invnormalize_bit_exact(golden):
+    g = golden("decode")
+    d, side = bio.normalize_data(g["vol"], "minmaxany_0_100")
+    assert np.array_equal(d.numpy(), g["norm_f32"])
+    assert [side["min"], side["max"]] == list(g["side_min_max"])
+    assert np.array_equal(bio.invnormalize_data(torch.from_numpy(g["inv_probe_in"].copy()), side, "minmaxany_0_100"), g["inv_probe_out"])
+    assert np.array_equal(bio.invnormalize_data(torch.from_numpy(g["dec_f32"].copy()), side, "minmaxany_0_100"), g["dec_u16"])
+    d8, side8 = bio.normalize_data(g["vol8"], "minmaxany_0_100")
+    assert np.array_equal(d8.numpy(), g["norm8_f32"]) and side8["dtype"] == "uint8"
+    assert np.array_equal(bio.invnormalize_data(d8.clone() * 0.97 + 1.0, side8, "minmaxany_0_100"), g["inv8"])
+
+
+def test_metrics(golden):
+    g = golden("decode")
+    v32, o32 = g["vol"].astype(np.float32), g["dec_u16"].astype(np.float32)
+    assert abs(metrics.cal_mse(v32, o32) - g["mse"][0]) / g["mse"][0] < 1e-6
+    assert abs(metrics.cal_psnr(v32, o32, 65535) - g["psnr"][0]) < 1e-4
+    assert abs(metrics.cal_ssim(v32, o32, 65535) - g["ssim"][0]) < 2e-5
+    a, b = g["pair_a"].astype(np.float32), g["pair_b"].astype(np.float32)
+    assert abs(metrics.cal_psnr(a, b, 65535) - g["pair_psnr"][0]) < 1e-4
+    assert abs(metrics.cal_ssim(a, b, 65535) - g["pair_ssim"][0]) < 2e-5
+    ia, ib = g["img_a"].astype(np.float32), g["img_b"].astype(np.float32)
+    assert abs(metrics.cal_psnr(ia, ib, 255) - g["img_psnr"][0]) < 1e-4
+    assert abs(metrics.cal_ssim(ia, ib, 255) - g["img_ssim"][0]) < 2e-5
+    perf = metrics.eval_performance(7, g["vol"], g["dec_u16"], None, True, True, True)
+    assert perf["steps"] == 7 and abs(perf["psnr"] - g["psnr"][0]) < 1e-4
+    sse = float(((g["vol"].astype(np.int64) - g["dec_u16"].astype(np.int64)) ** 2).sum())
+    assert abs(metrics.psnr_from_sse(sse, g["vol"].size, 65535) - g["psnr"][0]) < 1e-4
+
+
+def test_model_files_roundtrip(tmp_path, golden):
+    torch.manual_seed(3)
+    m = SIREN(features=22, layers=5, w0=20)
+    path = str(tmp_path / "module")
+    modelsave.save_model(m, path)
+    names = sorted(os.listdir(path))
+    assert names == sorted(["weight-0-22-3", "bias-0-22", "weight-1-22-22", "bias-1-22", "weight-2-22-22", "bias-2-22",
+                            "weight-3-22-22", "bias-3-22", "weight-4-1-22", "bias-4-1"])
+    assert bio.get_folder_size(path) == 4 * m.param_count
+    raw = np.fromfile(os.path.join(path, "weight-1-22-22"), dtype="<f4")    # row-major [out,in] float32
+    assert np.array_equal(raw.reshape(22, 22), m.net[1][0].weight.data.numpy())
+    torch.manual_seed(4)
+    m2 = SIREN(features=22, layers=5, w0=20)
+    modelsave.load_model(m2, path)
+    assert torch.equal(m2.params, m.params)
+    modelsave.CopyDir(path, str(tmp_path / "copy"))
+    assert sorted(os.listdir(str(tmp_path / "copy"))) == names
+
+
+def test_checkpoints_and_weights(golden):
+    g = golden("divide")
+    for i, key in enumerate(g["checkpoints_keys"]):
+        spec, ms = str(key).split("@")
+        assert misc.parse_checkpoints(spec, int(ms)) == list(g["checkpoints_%d" % i])
+    for i, spec in enumerate((["value_65535_65535_1"], ["value_17000_20000_0.1"], ["quantile_16000_0.2_0.8_0.5"], ["exp_20000_0.5"], ["none"])):
+        assert np.array_equal(misc.parse_weight(g["weight_vol"], spec), g["weight_%d" % i]), spec
+    assert misc.weights_are_trivial(["value_65535_65535_1"], g["vol"], 0, 0)
+    assert not misc.weights_are_trivial(["value_17000_20000_0.1"], g["vol"], 0, 0)
+
+
+@pytest.mark.parametrize("dt", ["total_2_2_2", "every_5_8_7", "total_1_2_4"])
+def test_divide_alloc_merge(golden, dt):
+    g = golden("divide")
+    vol = g["vol"]
+    chunks, outline = misc.divide_data(vol, dt)
+    assert [c["name"] for c in chunks] == list(g["names_" + dt])
+    assert [c["size"] for c in chunks] == list(g["sizes_" + dt])
+    assert outline.shape == vol.shape and (outline == 2000).any()
+    for alloc in ("equal", "by_size", "by_var", "by_d", "by_dv"):
+        import copy
+        ch = misc.alloc_param(copy.deepcopy(chunks), 40000.0, alloc, 26)
+        assert [c["name"] for c in ch] == list(g["alloc_%s_%s_names" % (dt, alloc)])
+        np.testing.assert_allclose([c["param_size"] for c in ch], g["alloc_%s_%s" % (dt, alloc)], rtol=1e-12)
+    dl = [{"data": c["data"].copy(), "name": c["name"], **misc.parse_chunk_name(c["name"])} for c in chunks]
+    assert np.array_equal(misc.merge_divided_data(dl, list(vol.shape)), g["merge_" + dt])
+    assert np.array_equal(g["merge_" + dt], vol)
+
+
+def test_budget_drop_and_divide_num(golden):
+    g = golden("divide")
+    import copy
+    chunks, _ = misc.divide_data(g["vol"], "every_11_16_20")
+    ch = misc.alloc_param(copy.deepcopy(chunks), 300.0, "by_size", 26)
+    assert [c["name"] for c in ch] == list(g["drop_names"])
+    np.testing.assert_allclose([c["param_size"] for c in ch], g["drop_sizes"], rtol=1e-12)
+    assert abs(misc.cal_feature(g["vol"]) - g["feature_vol"][0]) < 1e-15
+    for d, h, w, nb, nd, nh, nw in g["divide_num"]:
+        assert misc.cal_divide_num(int(d), int(h), int(w), int(nb), 1e6) == (nd, nh, nw)
+    assert misc.cal_divide_num(64, 64, 64, -1, 4 * 1361 * 9.5) == tuple(g["divide_num_auto"])
