@@ -28,6 +28,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include "brief_layout.h"
 #include "brief_math.h"
 
@@ -76,6 +77,9 @@ struct FusedArgs {
     void *out;           // forward output
     int out_kind;
     float scale_min, den, span, vmin;   // fused invnormalize
+    int dbg;             // ablation flags from BRIEF_DEBUG (timing experiments only)
+    int stagger_cus;     // workgroups per residency slot (= CU count)
+    int stagger;         // s_sleep(127) units of start delay per slot
 };
 
 // torch.linspace as torch-CPU evaluates it (utils/dataset.py:28-32)
@@ -108,20 +112,21 @@ __device__ __forceinline__ void bstore1(float v, __amdgpu_buffer_rsrc_t rs, int 
 // A fragments stream from the packed weight buffer (L2 resident) PD (kt,q)-steps ahead of use.
 template <int NT>
 __device__ __forceinline__ void chain(f32x16 (&acc)[KCfg<NT>::MTW], __amdgpu_buffer_rsrc_t rs, int soff_layer /*bytes*/,
-                                      const float4 *Xs, int wm, int lane)
+                                      const float4 *Xs, int wm, int lane, bool dbg_nol2 = false)
 {
     using K = KCfg<NT>;
     constexpr int NIT = NT * 4;
     constexpr int PD = NIT < 4 ? NIT : 4;
     const int voff = lane * 16;
     const int soff_w = soff_layer + wm * (NT * 4 * 1024);
+    const int smul = dbg_nol2 ? 0 : 1024;
     float4 areg[NIT][K::MTW];
     float4 breg[NIT];
 #pragma unroll
     for (int it = 0; it < PD; ++it)
 #pragma unroll
         for (int t = 0; t < K::MTW; ++t)
-            if (K::EXACT || wm + K::WM * t < NT) areg[it][t] = bload4(rs, voff, soff_w + (K::WM * t * NT * 4 + it) * 1024);
+            if (K::EXACT || wm + K::WM * t < NT) areg[it][t] = bload4(rs, voff, soff_w + (K::WM * t * NT * 4 + it) * smul);
     breg[0] = Xs[lane];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -129,7 +134,7 @@ __device__ __forceinline__ void chain(f32x16 (&acc)[KCfg<NT>::MTW], __amdgpu_buf
 #pragma unroll
             for (int t = 0; t < K::MTW; ++t)
                 if (K::EXACT || wm + K::WM * t < NT)
-                    areg[it + PD][t] = bload4(rs, voff, soff_w + (K::WM * t * NT * 4 + it + PD) * 1024);
+                    areg[it + PD][t] = bload4(rs, voff, soff_w + (K::WM * t * NT * 4 + it + PD) * smul);
         }
         if (it + 1 < NIT) breg[it + 1] = Xs[(it + 1) * 64 + lane];
         // pin the prefetch above this step's MFMAs: left alone, the scheduler sinks each load to
@@ -164,14 +169,41 @@ __device__ __forceinline__ void write_image(float4 *Xs, const f32x16 (&h)[KCfg<N
     }
 }
 
-template <int NT, bool TRAIN>
-__global__ __launch_bounds__(256, 2) void k_fused(const FusedArgs a)
-{
+// LDS map of k_fused (floats):  R = max(image, transpose scratch) | G (per-wave g / coords) | HW (head weights)
+//   image  X : WS x NT x 1024            activation register image(s)
+//   scratch T: 4 waves x 64 x 33          per-wave [feature][sample] transpose (aliases X: used only while
+//                                         no wave reads the image, see the barriers below)
+template <int NT>
+struct FusedLds {
     using K = KCfg<NT>;
+    static constexpr int R_FLOATS = K::XS_FLOATS > K::T_FLOATS ? K::XS_FLOATS : K::T_FLOATS;
+    static constexpr int G_OFF = R_FLOATS;
+    static constexpr int HW_OFF = G_OFF + K::G_FLOATS;
+    static constexpr int TOTAL = HW_OFF + 4 * K::FP + 4;
+};
+
+#ifndef BRIEF_TRAIN_WPE
+#define BRIEF_TRAIN_WPE 2   // waves per SIMD the TRAIN variant is register-allocated for
+#endif
+#ifdef BRIEF_STAMPS
+#define STAMP(slot) { const long long t_ = clock64(); st_acc[slot] += (float)(t_ - st_last); st_last = t_; }
+#else
+#define STAMP(slot)
+#endif
+template <int NT, bool TRAIN>
+__global__ __launch_bounds__(256, TRAIN ? BRIEF_TRAIN_WPE : 3) void k_fused(const FusedArgs a)
+{
+#ifdef BRIEF_STAMPS
+    float st_acc[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    long long st_last = clock64();
+#endif
+    using K = KCfg<NT>;
+    using LD = FusedLds<NT>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float4 *X = reinterpret_cast<float4 *>(smem);
-    float *T = smem + K::XS_FLOATS;
-    float *G = T + K::T_FLOATS;
+    float *T = smem;                       // aliases X
+    float *G = smem + LD::G_OFF;
+    float *HW = smem + LD::HW_OFF;         // Whp[4][FP], bhp[4]
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -185,11 +217,24 @@ __global__ __launch_bounds__(256, 2) void k_fused(const FusedArgs a)
     float *Tw = T + wave * (64 * 33);
     float *Gw = G + wave * 256;
     const float4 *W0p = reinterpret_cast<const float4 *>(pk + brief_pk_w0(d));
-    const float *headp = pk + brief_pk_head(d);   // Whp[4][FP] then bhp[4]
     const __amdgpu_buffer_rsrc_t rs_pk =
         __builtin_amdgcn_make_buffer_rsrc((void *)pk, 0, (int)(brief_pk_count(d) * 4), 0x00020000);
     const int stash_bytes = (int)((int64_t)K::FP * npad * 4);   // one [FP][npad] panel (host checks < 2^31)
-    const int row_bytes = (int)(npad * 4);
+    const int row_bytes = (a.dbg & 2) ? 0 : (int)(npad * 4);
+    const bool nol2 = (a.dbg & 1) != 0;
+
+    // head weights -> LDS once per workgroup (every lane needs all of them in the head dot product)
+    {
+        const float *headp = pk + brief_pk_head(d);
+        for (int e = threadIdx.x; e < 4 * K::FP + 4; e += 256) HW[e] = headp[e];
+    }
+    // de-phase the co-resident workgroups: started together they run their MFMA chains and their
+    // epilogues in lockstep and the matrix pipe idles through every epilogue
+    {
+        const int slot = blockIdx.x / a.stagger_cus;
+        for (int i = 0; i < slot * a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+    __syncthreads();
 
     // persistent skinny-gradient accumulators (lane <-> local feature)
     float acc0[4] = {0.f, 0.f, 0.f, 0.f};
@@ -203,11 +248,22 @@ __global__ __launch_bounds__(256, 2) void k_fused(const FusedArgs a)
         const int64_t n0 = (tile * K::WS + ws) * 32;
         const int64_t n = n0 + ln;
         const bool valid = n < a.n;
-        // ---- sample inputs (every wave of the sample tile computes them; they are tiny)
+        // ---- sample inputs (every wave of the sample tile fetches them; they are tiny).  Targets and
+        //      weights are fetched now although the loss needs them a whole forward pass later.
         int64_t j = 0;
         if (valid) j = a.idx ? a.idx[n] : n + a.offset;
         float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+        float yv[4] = {0.f, 0.f, 0.f, 0.f}, wv4[4] = {1.f, 1.f, 1.f, 1.f};
         if (valid) {
+            if (TRAIN) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (c < cout) {
+                        yv[c] = a.targets[j * cout + c];
+                        if (a.weights) wv4[c] = a.weights[j * cout + c];
+                    }
+                }
+            }
             if (a.coords) {
                 x0 = a.coords[j * cin];
                 x1 = a.coords[j * cin + 1];
@@ -227,10 +283,25 @@ __global__ __launch_bounds__(256, 2) void k_fused(const FusedArgs a)
         f32x16 acc[K::MTW];
         f32x16 creg[K::MTW];   // w*cos(w z) of the last sine layer (TRAIN)
         f32x16 hreg[K::MTW];
+        float4 bnext[K::MTW][4];   // next hidden layer's bias, fetched one epilogue ahead of its use
 #pragma unroll
-        for (int t = 0; t < K::MTW; ++t)
+        for (int t = 0; t < K::MTW; ++t) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { creg[t][r] = 0.f; hreg[t][r] = 0.f; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bnext[t][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#define FUSED_LOAD_BIAS(layer)                                                                          \
+    {                                                                                                   \
+        const float *bp_ = pk + brief_pk_hidden(d, (layer)) + 2 * K::FP * K::FP;                        \
+        _Pragma("unroll") for (int t = 0; t < K::MTW; ++t) {                                            \
+            const int mt = wm + K::WM * t;                                                              \
+            if (K::EXACT || mt < NT) {                                                                  \
+                _Pragma("unroll") for (int q = 0; q < 4; ++q)                                           \
+                    bnext[t][q] = *reinterpret_cast<const float4 *>(bp_ + 32 * mt + 8 * q + 4 * hi);    \
+            }                                                                                           \
+        }                                                                                               \
+    }
         // ---- layer 0: z0 = W0 x + b0 as two K=2 MFMAs ([x0 x1 | x2 1] against W0p rows)
         {
             const float b0 = hi ? x1 : x0;
@@ -247,26 +318,26 @@ __global__ __launch_bounds__(256, 2) void k_fused(const FusedArgs a)
                 }
             }
         }
+        STAMP(0)
         // ---- sine layers 0 .. L-2
         for (int l = 0; l <= L - 2; ++l) {
             const float om = l == 0 ? d.w0_first : d.w0_hidden;
             const bool last = (l == L - 2);
             if (l > 0) {
-                const float *blk = pk + brief_pk_hidden(d, l);
-                const float *bp = blk + 2 * K::FP * K::FP;
 #pragma unroll
                 for (int t = 0; t < K::MTW; ++t) {
-                    const int mt = wm + K::WM * t;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (K::EXACT || mt < NT) bb = *reinterpret_cast<const float4 *>(bp + 32 * mt + 8 * q + 4 * hi);
-                        acc[t][4 * q] = bb.x; acc[t][4 * q + 1] = bb.y; acc[t][4 * q + 2] = bb.z; acc[t][4 * q + 3] = bb.w;
+                        acc[t][4 * q] = bnext[t][q].x; acc[t][4 * q + 1] = bnext[t][q].y;
+                        acc[t][4 * q + 2] = bnext[t][q].z; acc[t][4 * q + 3] = bnext[t][q].w;
                     }
                 }
-                chain<NT>(acc, rs_pk, (int)(brief_pk_hidden(d, l) * 4), Xs, wm, lane);
+                chain<NT>(acc, rs_pk, (int)(brief_pk_hidden(d, l) * 4), Xs, wm, lane, nol2);
+                STAMP(1)
                 __syncthreads();   // every wave is done reading the previous image
+                STAMP(2)
             }
+            if (!last) FUSED_LOAD_BIAS(l + 1)   // lands while this epilogue computes its sines
             // epilogue: stash z, h = sin(om z) (+ c = om cos(om z) on the last sine layer)
 #pragma unroll
             for (int t = 0; t < K::MTW; ++t) {
@@ -282,15 +353,16 @@ __global__ __launch_bounds__(256, 2) void k_fused(const FusedArgs a)
                     }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        float s, c;
-                        brief_sincosf(om * acc[t][r], &s, &c);
-                        hreg[t][r] = s;
-                        if (TRAIN && last) creg[t][r] = om * c;
+                        const float fr = brief_revolutions(om * acc[t][r]);
+                        hreg[t][r] = BRIEF_SIN_REV(fr);
+                        if (TRAIN && last) creg[t][r] = om * BRIEF_COS_REV(fr);
                     }
                 }
             }
             write_image<NT>(Xs, hreg, wm, lane);
+            STAMP(3)
             __syncthreads();
+            STAMP(4)
         }
         // ---- head (every wave evaluates it for its sample tile; F MACs per sample)
         float zo[4], yh[4], g[4];
@@ -299,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void k_fused(const FusedArgs a)
             zo[c] = 0.f; yh[c] = 0.f; g[c] = 0.f;
             if (c < cout) {
                 float p = 0.f;
-                const float *wrow = headp + c * K::FP;
+                const float *wrow = HW + c * K::FP;
 #pragma unroll
                 for (int kt = 0; kt < NT; ++kt) {
 #pragma unroll
@@ -311,8 +383,8 @@ __global__ __launch_bounds__(256, 2) void k_fused(const FusedArgs a)
                     }
                 }
                 p += __shfl_xor(p, 32);
-                zo[c] = p + headp[4 * K::FP + c];
-                yh[c] = d.output_act ? brief_sinf(d.w0_hidden * zo[c]) : zo[c];
+                zo[c] = p + HW[4 * K::FP + c];
+                yh[c] = d.output_act ? brief_fast_sinf(d.w0_hidden * zo[c]) : zo[c];
             }
         }
         if (!TRAIN) {
@@ -340,10 +412,9 @@ __global__ __launch_bounds__(256, 2) void k_fused(const FusedArgs a)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             if (c < cout && valid) {
-                const float y = a.targets[j * cout + c];
-                float we = a.weights ? a.weights[j * cout + c] : 1.0f;
+                float we = wv4[c];
                 if (a.thr != 0.f && yh[c] <= a.thr) we = 1.0f;
-                const float df = yh[c] - y;
+                const float df = yh[c] - yv[c];
                 float li, gi;
                 if (a.loss_kind == BRIEF_LOSS_L2) { li = df * df; gi = 2.0f * df; }
                 else {
@@ -353,11 +424,14 @@ __global__ __launch_bounds__(256, 2) void k_fused(const FusedArgs a)
                 }
                 if (wm == 0 && hi == 0) lsum += li * we;
                 g[c] = gi * we * a.inv_count;
-                if (d.output_act) g[c] *= d.w0_hidden * brief_cosf(d.w0_hidden * zo[c]);
+                if (d.output_act) g[c] *= d.w0_hidden * brief_fast_cosf(d.w0_hidden * zo[c]);
                 if (a.yhat_out && wm == 0 && hi == 0) a.yhat_out[n * cout + c] = yh[c];
             }
         }
-        // ---- head gradients: transpose own h tiles through LDS, lane <-> local feature
+        STAMP(5)
+        // ---- head gradients: transpose own h tiles through LDS (scratch aliases the image: every
+        //      wave must be past its head reads first), lane <-> local feature
+        __syncthreads();
 #pragma unroll
         for (int t = 0; t < K::MTW; ++t) {
 #pragma unroll
@@ -394,7 +468,7 @@ __global__ __launch_bounds__(256, 2) void k_fused(const FusedArgs a)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         if (c < cout) {
-                            const float4 wv = *reinterpret_cast<const float4 *>(headp + c * K::FP + 32 * mt + 8 * q + 4 * hi);
+                            const float4 wv = *reinterpret_cast<const float4 *>(HW + c * K::FP + 32 * mt + 8 * q + 4 * hi);
                             sacc.x = __fmaf_rn(wv.x, g[c], sacc.x); sacc.y = __fmaf_rn(wv.y, g[c], sacc.y);
                             sacc.z = __fmaf_rn(wv.z, g[c], sacc.z); sacc.w = __fmaf_rn(wv.w, g[c], sacc.w);
                         }
@@ -404,6 +478,7 @@ __global__ __launch_bounds__(256, 2) void k_fused(const FusedArgs a)
                 }
             }
         }
+        STAMP(6)
         // ---- dgrad chain: layers L-2 .. 1
         for (int l = L - 2; l >= 1; --l) {
             // stash delta_l for the weight-gradient GEMM and publish it as the B image
@@ -419,30 +494,43 @@ __global__ __launch_bounds__(256, 2) void k_fused(const FusedArgs a)
                         bstore1(dl[t][r], rd, voff_s, (32 * mt + (r & 3) + 8 * (r >> 2)) * row_bytes);
                 }
             }
-            __syncthreads();   // head / previous chain finished with the image
+            // z_{l-1} comes back from the stash while the chain runs (it is only needed after it)
+            const __amdgpu_buffer_rsrc_t rzp =
+                __builtin_amdgcn_make_buffer_rsrc((void *)(a.Z + (int64_t)(l - 1) * K::FP * npad), 0, stash_bytes, 0x00020000);
+            float zr[K::MTW][16];
+#pragma unroll
+            for (int t = 0; t < K::MTW; ++t) {
+                const int mt = wm + K::WM * t;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    zr[t][r] = 0.f;
+                    if (K::EXACT || mt < NT) zr[t][r] = bload1(rzp, voff_s, (32 * mt + (r & 3) + 8 * (r >> 2)) * row_bytes);
+                }
+            }
+            STAMP(7)
+            __syncthreads();   // transpose scratch / previous chain finished with the image region
             write_image<NT>(Xs, dl, wm, lane);
             __syncthreads();
+            STAMP(8)
 #pragma unroll
             for (int t = 0; t < K::MTW; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-            chain<NT>(acc, rs_pk, (int)((brief_pk_hidden(d, l) + K::FP * K::FP) * 4), Xs, wm, lane);
-            // delta_{l-1} = acc * om cos(om z_{l-1}), z re-read from the stash
+            chain<NT>(acc, rs_pk, (int)((brief_pk_hidden(d, l) + K::FP * K::FP) * 4), Xs, wm, lane, nol2);
+            STAMP(9)
+            // delta_{l-1} = acc * om cos(om z_{l-1})
             const float om = (l - 1) == 0 ? d.w0_first : d.w0_hidden;
-            const __amdgpu_buffer_rsrc_t rzp =
-                __builtin_amdgcn_make_buffer_rsrc((void *)(a.Z + (int64_t)(l - 1) * K::FP * npad), 0, stash_bytes, 0x00020000);
 #pragma unroll
             for (int t = 0; t < K::MTW; ++t) {
                 const int mt = wm + K::WM * t;
                 if (K::EXACT || mt < NT) {
-                    float zr[16];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) zr[r] = bload1(rzp, voff_s, (32 * mt + (r & 3) + 8 * (r >> 2)) * row_bytes);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) dl[t][r] = acc[t][r] * om * brief_cosf(om * zr[r]);
+                    for (int r = 0; r < 16; ++r)
+                        dl[t][r] = acc[t][r] * om * brief_fast_cosf(om * zr[t][r]);
                 }
             }
         }
+        STAMP(7)
         // ---- first-layer gradients from delta_0 (lane <-> local feature)
         __syncthreads();
 #pragma unroll
@@ -464,7 +552,9 @@ __global__ __launch_bounds__(256, 2) void k_fused(const FusedArgs a)
             if (lane < 32 * K::MTW) { acc0[0] += s0.x; acc0[1] += s0.y; acc0[2] += s0.z; acc0[3] += s0.w; }
         }
         __syncthreads();
+        STAMP(6)
     }
+#undef FUSED_LOAD_BIAS
     if (TRAIN) {
         float *rec = a.rec + ((int64_t)blockIdx.x * 4 + wave) * BRIEF_REC_FLOATS;
 #pragma unroll
@@ -477,6 +567,9 @@ __global__ __launch_bounds__(256, 2) void k_fused(const FusedArgs a)
 #pragma unroll
             for (int c = 0; c < 4; ++c) rec[512 + c] = accbh[c];
             rec[516] = lsum;
+#ifdef BRIEF_STAMPS
+            for (int i = 0; i < 10; ++i) rec[518 + i] = st_acc[i];
+#endif
         }
     }
 }
@@ -498,10 +591,12 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
     constexpr int FP = 32 * NT;
     constexpr int WMk = 2, WNk = 4;
     constexpr int TM = (NT + WMk - 1) / WMk, TN = (NT + WNk - 1) / WNk;
+    constexpr bool MEX = NT % WMk == 0, NEX = NT % WNk == 0;   // every wave tile exists
     constexpr int LDSW = 36;                       // row stride (floats): conflict-free ds_read_b128
     constexpr int NLD = (FP * 8 + 511) / 512;      // float4 loads per thread per operand per chunk
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *As = smem, *Bs = smem + FP * LDSW;
+    constexpr int PANEL = FP * LDSW;
+    constexpr bool FULL = (FP * 8) % 512 == 0;     // every thread has a slot in every staging pass
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2 buffers][A panel | B panel]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -511,7 +606,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
     const int l = 1 + blockIdx.x / a.nsplit;       // hidden layer 1..L-2
     const int split = blockIdx.x % a.nsplit;
     const int64_t nchunks = a.npad / 32;
-    const int64_t c0 = nchunks * split / a.nsplit, c1 = nchunks * (split + 1) / a.nsplit;
+    const int64_t c0 = nchunks * split / a.nsplit, c1 = nchunks * (split + 1) / a.nsplit;   // c1 > c0 (host: nsplit <= nchunks)
     const float om = (l - 1) == 0 ? a.d.w0_first : a.d.w0_hidden;
     const float *Dl = a.D + (int64_t)(l - 1) * FP * a.npad;
     const float *Zl = a.Z + (int64_t)(l - 1) * FP * a.npad;
@@ -527,33 +622,48 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
             for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
     }
     float4 ra[NLD], rb[NLD];
-    auto issue = [&](int64_t c) {
+    // The loop body is branch-free: the prefetch of "chunk c+2" and the staging of "chunk c+1" are
+    // clamped to the last chunk instead of being skipped (the redundant copies are never read).
+#define WG_ISSUE(cc)                                                                              \
+    _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                             \
+        const int e = tid + 512 * i;                                                              \
+        ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);                                                  \
+        rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);                                                  \
+        if (FULL || e < FP * 8) {                                                                 \
+            const int64_t off = (int64_t)(e >> 3) * a.npad + (cc) * 32 + (e & 7) * 4;             \
+            ra[i] = *reinterpret_cast<const float4 *>(Dl + off);                                  \
+            rb[i] = *reinterpret_cast<const float4 *>(Zl + off);                                  \
+        }                                                                                         \
+    }
+#define WG_STAGE_A(buf, i)                                                                        \
+    {                                                                                             \
+        const int e = tid + 512 * (i);                                                            \
+        if (FULL || e < FP * 8)                                                                   \
+            *reinterpret_cast<float4 *>(smem + (buf) * 2 * PANEL + (e >> 3) * LDSW + (e & 7) * 4) = ra[i]; \
+    }
+#define WG_STAGE_B(buf, i)                                                                        \
+    {                                                                                             \
+        const int e = tid + 512 * (i);                                                            \
+        if (FULL || e < FP * 8) {                                                                 \
+            float4 h;                                                                             \
+            h.x = brief_fast_sinf(om * rb[i].x); h.y = brief_fast_sinf(om * rb[i].y);             \
+            h.z = brief_fast_sinf(om * rb[i].z); h.w = brief_fast_sinf(om * rb[i].w);             \
+            *reinterpret_cast<float4 *>(smem + (buf) * 2 * PANEL + PANEL + (e >> 3) * LDSW + (e & 7) * 4) = h; \
+        }                                                                                         \
+    }
+    WG_ISSUE(c0)
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int e = tid + 512 * i;           // float4 slot: row = e/8, col4 = e%8
-            if (e < FP * 8) {
-                const int64_t off = (int64_t)(e >> 3) * a.npad + c * 32 + (e & 7) * 4;
-                ra[i] = *reinterpret_cast<const float4 *>(Dl + off);
-                rb[i] = *reinterpret_cast<const float4 *>(Zl + off);
-            }
-        }
-    };
-    if (c0 < c1) issue(c0);
+    for (int i = 0; i < NLD; ++i) { WG_STAGE_A(0, i) WG_STAGE_B(0, i) }
+    {
+        const int64_t cn = c0 + 1 < c1 ? c0 + 1 : c1 - 1;
+        WG_ISSUE(cn)
+    }
+    __syncthreads();
     for (int64_t c = c0; c < c1; ++c) {
+        const int cur = (int)(c - c0) & 1;
+        const float *As = smem + cur * 2 * PANEL, *Bs = As + PANEL;
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int e = tid + 512 * i;
-            if (e < FP * 8) {
-                const int o = (e >> 3) * LDSW + (e & 7) * 4;
-                *reinterpret_cast<float4 *>(As + o) = ra[i];
-                float4 h;
-                h.x = brief_sinf(om * rb[i].x); h.y = brief_sinf(om * rb[i].y);
-                h.z = brief_sinf(om * rb[i].z); h.w = brief_sinf(om * rb[i].w);
-                *reinterpret_cast<float4 *>(Bs + o) = h;
-            }
-        }
-        __syncthreads();
-        if (c + 1 < c1) issue(c + 1);
+        for (int i = 0; i < NLD; ++i) WG_STAGE_A(cur ^ 1, i)
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
             float4 af[TM], bf[TN];
@@ -561,20 +671,20 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
             for (int i = 0; i < TM; ++i) {
                 const int mt = wmk * TM + i;
                 af[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (mt < NT) af[i] = *reinterpret_cast<const float4 *>(As + (32 * mt + ln) * LDSW + 8 * gq + 4 * hi);
-                if (wnk == 0) dbacc[i] += (af[i].x + af[i].y) + (af[i].z + af[i].w);
+                if (MEX || mt < NT) af[i] = *reinterpret_cast<const float4 *>(As + (32 * mt + ln) * LDSW + 8 * gq + 4 * hi);
+                dbacc[i] += (af[i].x + af[i].y) + (af[i].z + af[i].w);
             }
 #pragma unroll
             for (int jn = 0; jn < TN; ++jn) {
                 const int nt = wnk * TN + jn;
                 bf[jn] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (nt < NT) bf[jn] = *reinterpret_cast<const float4 *>(Bs + (32 * nt + ln) * LDSW + 8 * gq + 4 * hi);
+                if (NEX || nt < NT) bf[jn] = *reinterpret_cast<const float4 *>(Bs + (32 * nt + ln) * LDSW + 8 * gq + 4 * hi);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
 #pragma unroll
                 for (int jn = 0; jn < TN; ++jn) {
-                    if (wmk * TM + i < NT && wnk * TN + jn < NT) {
+                    if ((MEX || wmk * TM + i < NT) && (NEX || wnk * TN + jn < NT)) {
                         acc[i][jn] = MFMA(af[i].x, bf[jn].x, acc[i][jn]);
                         acc[i][jn] = MFMA(af[i].y, bf[jn].y, acc[i][jn]);
                         acc[i][jn] = MFMA(af[i].z, bf[jn].z, acc[i][jn]);
@@ -582,9 +692,20 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
                     }
                 }
             }
+            // a slice of the next chunk's staging rides in the shadow of this group's MFMAs
+#pragma unroll
+            for (int i = 0; i < NLD; ++i)
+                if ((i & 3) == gq) WG_STAGE_B(cur ^ 1, i)
+        }
+        {
+            const int64_t cn = c + 2 < c1 ? c + 2 : c1 - 1;
+            WG_ISSUE(cn)
         }
         __syncthreads();
     }
+#undef WG_ISSUE
+#undef WG_STAGE_A
+#undef WG_STAGE_B
     float *slab = a.slabs + ((int64_t)(l - 1) * a.nsplit + split) * ((int64_t)FP * FP + FP);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -837,11 +958,17 @@ static bool g_prof_init = false;
 static const int kMaxFusedGrid = 512;   // 2 resident workgroups per CU on 256 CUs
 static const int kWgradBlocks = 256;
 
-static int fused_grid(const brief_siren_desc &d, int64_t n)
+// persistent grid: g_wg_per_cu workgroups per CU, each walking tiles blockIdx, blockIdx+grid, ...
+static const int kCUs = 256;            // MI355X
+static int g_wg_per_cu = BRIEF_TRAIN_WPE;   // resident k_fused<TRAIN> workgroups per CU
+static int g_stagger = 1;               // start delay per residency slot, units of s_sleep(127)
+static int fused_grid(const brief_siren_desc &d, int64_t n, bool train)
 {
+    (void)train;
     const int nt = brief_nt(d);
     const int64_t tiles = (n + brief_wg_samples(nt) - 1) / brief_wg_samples(nt);
-    return (int)(tiles < kMaxFusedGrid ? (tiles > 0 ? tiles : 1) : kMaxFusedGrid);
+    const int64_t cap = (int64_t)kCUs * g_wg_per_cu;
+    return (int)(tiles < cap ? (tiles > 0 ? tiles : 1) : cap);
 }
 static int wgrad_splits(const brief_siren_desc &d, int64_t n)
 {
@@ -863,7 +990,7 @@ static WsLayout ws_layout(const brief_siren_desc &d, int64_t n)
     w.z = 0;
     w.dd = w.z + hidden * FP * npad;
     w.rec = w.dd + hidden * FP * npad;
-    w.slabs = w.rec + (int64_t)kMaxFusedGrid * 4 * BRIEF_REC_FLOATS;
+    w.slabs = w.rec + (int64_t)kCUs * 4 /*max wg/CU*/ * 4 * BRIEF_REC_FLOATS;
     w.total = w.slabs + hidden * (int64_t)wgrad_splits(d, n) * (FP * FP + FP);
     return w;
 }
@@ -911,8 +1038,7 @@ static int launch_fused(const FusedArgs &fa, int grid, hipStream_t st)
     const int nt = brief_nt(fa.d);
 #define BRIEF_CASE(NTV)                                                                                  \
     case NTV: {                                                                                          \
-        using K = KCfg<NTV>;                                                                             \
-        const size_t lds = sizeof(float) * (K::XS_FLOATS + (TRAIN ? K::T_FLOATS + K::G_FLOATS : 0));     \
+        const size_t lds = sizeof(float) * FusedLds<NTV>::TOTAL;                                         \
         hipLaunchKernelGGL((k_fused<NTV, TRAIN>), dim3(grid), dim3(256), lds, st, fa);                   \
         break;                                                                                           \
     }
@@ -959,7 +1085,8 @@ int brief_siren_forward(const brief_siren_desc *d, const float *packed, const br
     fa.den = (float)((double)scale_max - (double)scale_min);
     fa.span = (float)(vmax - vmin);
     fa.vmin = (float)vmin;
-    return launch_fused<false>(fa, fused_grid(*d, batch->n), (hipStream_t)stream);
+    fa.stagger_cus = kCUs; fa.stagger = 0;
+    return launch_fused<false>(fa, fused_grid(*d, batch->n, false), (hipStream_t)stream);
 }
 
 int brief_siren_train_step(const brief_siren_desc *d, const float *packed, const brief_grid_desc *grid,
@@ -976,7 +1103,9 @@ int brief_siren_train_step(const brief_siren_desc *d, const float *packed, const
     hipStream_t st = (hipStream_t)stream;
     float *ws = (float *)workspace;
     const int nt = brief_nt(*d);
-    const int grid1 = fused_grid(*d, batch->n);
+    if (const char *e = getenv("BRIEF_WG_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 4) g_wg_per_cu = v; }
+    if (const char *e = getenv("BRIEF_STAGGER")) g_stagger = atoi(e);
+    const int grid1 = fused_grid(*d, batch->n, true);
     const int nsplit = wgrad_splits(*d, batch->n);
     const float inv_count = (float)(1.0 / ((double)batch->n * d->cout));
 
@@ -989,6 +1118,8 @@ int brief_siren_train_step(const brief_siren_desc *d, const float *packed, const
     fa.loss_kind = loss_kind; fa.thr = thr; fa.beta = beta; fa.inv_count = inv_count;
     fa.Z = ws + wl.z; fa.D = ws + wl.dd; fa.npad = brief_npad(nt, batch->n);
     fa.rec = ws + wl.rec; fa.yhat_out = yhat_out;
+    if (const char *e = getenv("BRIEF_DEBUG")) fa.dbg = atoi(e);
+    fa.stagger_cus = kCUs; fa.stagger = g_stagger;
     const bool prof = g_prof_on && g_prof_n < kProfSlots;
     if (prof) HIP_TRY(hipEventRecord(g_prof_ev[2 * g_prof_n], st));
     if (int rc = launch_fused<true>(fa, grid1, st)) return rc;
@@ -1001,7 +1132,7 @@ int brief_siren_train_step(const brief_siren_desc *d, const float *packed, const
         const int blocks = nsplit * (d->layers - 2);
 #define BRIEF_CASE(NTV)                                                                                    \
     case NTV:                                                                                              \
-        hipLaunchKernelGGL((k_wgrad<NTV>), dim3(blocks), dim3(512), sizeof(float) * 2 * 32 * NTV * 36, st, wa); \
+        hipLaunchKernelGGL((k_wgrad<NTV>), dim3(blocks), dim3(512), sizeof(float) * 4 * 32 * NTV * 36, st, wa); \
         break;
         switch (nt) {
             BRIEF_CASE(1) BRIEF_CASE(2) BRIEF_CASE(3) BRIEF_CASE(4)

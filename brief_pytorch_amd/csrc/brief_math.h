@@ -52,3 +52,33 @@ BRIEF_HD float brief_cosf(float x)
     brief_sincosf(x, &s, &c);
     return c;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Hot-path variant.  Measured on MI355X (tools/valu_mfma_ubench.hip): v_mfma_f32_32x32x2_f32 and
+// ordinary VALU instructions do NOT overlap on a SIMD (the f32 MFMA runs on the vector FMA lanes:
+// MFMA-only 1.88 ms + VALU-only 2.60 ms = 4.61 ms together), so every VALU instruction in an
+// epilogue is paid in matrix throughput.  v_sin_f32 / v_cos_f32 take REVOLUTIONS and are accurate to
+// 1.25e-7 abs on [-0.5, 0.5]; what they lack is an accurate reduction.  This does the reduction in
+// two fused steps with 1/(2 pi) split hi+lo (argument error <= 1.9e-7 rad for |x| <= 200) and then
+// uses the hardware ops: 5 VALU + 1-2 transcendental instead of ~30 VALU.  Total |err| <= ~3.1e-7.
+BRIEF_HD float brief_revolutions(float x)
+{
+    const float k = rintf(x * 0.15915494309189535f);
+    float f = fmaf(x, 0.15915493667125702f, -k);
+    return fmaf(x, 6.4206382432985265e-09f, f);
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BRIEF_SIN_REV(f) __builtin_amdgcn_sinf(f)
+#define BRIEF_COS_REV(f) __builtin_amdgcn_cosf(f)
+#else
+#define BRIEF_SIN_REV(f) ((float)sin(6.283185307179586476925 * (double)(f)))
+#define BRIEF_COS_REV(f) ((float)cos(6.283185307179586476925 * (double)(f)))
+#endif
+BRIEF_HD float brief_fast_sinf(float x) { return BRIEF_SIN_REV(brief_revolutions(x)); }
+BRIEF_HD float brief_fast_cosf(float x) { return BRIEF_COS_REV(brief_revolutions(x)); }
+BRIEF_HD void brief_fast_sincosf(float x, float *s, float *c)
+{
+    const float f = brief_revolutions(x);
+    *s = BRIEF_SIN_REV(f);
+    *c = BRIEF_COS_REV(f);
+}

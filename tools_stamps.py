@@ -1,0 +1,27 @@
+"""scratch: read the cycle stamps of the diagnostic k_fused build"""
+import shutil, sys
+shutil.copy('brief_pytorch_amd/libbrief_hip_stamps.so', 'brief_pytorch_amd/libbrief_hip.so')
+import torch, numpy as np
+sys.path.insert(0, '.')
+from brief_pytorch_amd import _lib
+from brief_pytorch_amd.networks import SIREN
+from brief_pytorch_amd.fit import Fitter
+torch.manual_seed(0)
+pop = 256**3
+m = SIREN(features=256, layers=5, w0=20).to('cuda')
+tv = torch.rand(pop, 1, device='cuda') * 100
+fit = Fitter(m, tv, (256,256,256), sample_size=100000)
+for _ in range(5): fit.step()
+torch.cuda.synchronize()
+FP, npad, hidden = 256, 100000, 3
+rec_off = 2 * hidden * FP * npad
+nrec = 512 * 4
+rec = m._ws[rec_off:rec_off + nrec * 528].view(nrec, 528).cpu().numpy()
+st = rec[:, 518:528]
+names = ['inputs+layer0', 'fwd chain', 'barrier after chain', 'fwd epilogue(stash,sincos,image)', 'barrier after image', 'head+loss',
+         'head-grad + delta + d0 transposes', 'D store + z prefetch', 'barriers+image before bwd chain', 'bwd chain']
+tot = st.sum(1)
+print('waves with stamps:', (tot > 0).sum(), 'mean total cycles/wave: %.0f' % tot[tot > 0].mean())
+for i, nme in enumerate(names):
+    v = st[tot > 0, i]
+    print('%-36s mean %9.0f cycles  %5.1f%%   (min %9.0f max %9.0f)' % (nme, v.mean(), 100 * v.mean() / tot[tot > 0].mean(), v.min(), v.max()))
