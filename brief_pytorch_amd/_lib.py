@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbrief_hip.so")
+LIB_PATH = os.environ.get("BRIEF_LIB", os.path.join(_HERE, "libbrief_hip.so"))   # BRIEF_LIB: A/B diagnostics only
 SRC = os.path.join(_HERE, "csrc", "brief_hip.hip")
 _DEPS = [SRC, os.path.join(_HERE, "csrc", "brief_layout.h"), os.path.join(_HERE, "csrc", "brief_math.h"),
          os.path.join(os.path.dirname(_HERE), "include", "brief_hip.h")]

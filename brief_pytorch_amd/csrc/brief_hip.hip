@@ -82,6 +82,17 @@ struct FusedArgs {
     int stagger;         // s_sleep(127) units of start delay per slot
 };
 
+// Workgroup barrier for LDS hand-offs only.  __syncthreads() also emits s_waitcnt vmcnt(0), which
+// drains every global load / store still in flight (register prefetches, stash stores) at each
+// barrier; all cross-wave traffic in these kernels goes through LDS, so waiting for the LDS queue is
+// enough (cdna_hip_programming.md, 'Pipelining across barriers').
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // torch.linspace as torch-CPU evaluates it (utils/dataset.py:28-32)
 __device__ __forceinline__ float lin_coord(const GridArgs &g, int a, int64_t i)
 {
@@ -118,7 +129,10 @@ __device__ __forceinline__ void chain(f32x16 (&acc)[KCfg<NT>::MTW], __amdgpu_buf
     constexpr int NIT = NT * 4;
     constexpr int PD = NIT < 4 ? NIT : 4;
     const int voff = lane * 16;
-    const int soff_w = soff_layer + wm * (NT * 4 * 1024);
+    int soff_w = soff_layer + wm * (NT * 4 * 1024);
+    // opaque to the optimiser: otherwise all 2*NT*4 per-block scalar offsets are hoisted out of the tile
+    // loop, spilled to VGPR lanes and fetched back with v_readlane (a VALU op the f32 MFMA has to wait for)
+    asm volatile("" : "+s"(soff_w));
     const int smul = dbg_nol2 ? 0 : 1024;
     float4 areg[NIT][K::MTW];
     float4 breg[NIT];
@@ -234,7 +248,7 @@ __global__ __launch_bounds__(256, TRAIN ? BRIEF_TRAIN_WPE : 3) void k_fused(cons
         const int slot = blockIdx.x / a.stagger_cus;
         for (int i = 0; i < slot * a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     }
-    __syncthreads();
+    lds_barrier();
 
     // persistent skinny-gradient accumulators (lane <-> local feature)
     float acc0[4] = {0.f, 0.f, 0.f, 0.f};
@@ -334,7 +348,7 @@ __global__ __launch_bounds__(256, TRAIN ? BRIEF_TRAIN_WPE : 3) void k_fused(cons
                 }
                 chain<NT>(acc, rs_pk, (int)(brief_pk_hidden(d, l) * 4), Xs, wm, lane, nol2);
                 STAMP(1)
-                __syncthreads();   // every wave is done reading the previous image
+                lds_barrier();   // every wave is done reading the previous image
                 STAMP(2)
             }
             if (!last) FUSED_LOAD_BIAS(l + 1)   // lands while this epilogue computes its sines
@@ -346,10 +360,12 @@ __global__ __launch_bounds__(256, TRAIN ? BRIEF_TRAIN_WPE : 3) void k_fused(cons
                     if (TRAIN && !last) {
                         const __amdgpu_buffer_rsrc_t rz =
                             __builtin_amdgcn_make_buffer_rsrc((void *)(a.Z + (int64_t)l * K::FP * npad), 0, stash_bytes, 0x00020000);
-                        const int voff = (int)(n * 4) + hi * 4 * row_bytes;
+                        int rbz = row_bytes;
+                        asm volatile("" : "+s"(rbz));      // keep the 16 row offsets in-loop scalar math
+                        const int voff = (int)(n * 4) + hi * 4 * rbz;
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
-                            bstore1(acc[t][r], rz, voff, (32 * mt + (r & 3) + 8 * (r >> 2)) * row_bytes);
+                            bstore1(acc[t][r], rz, voff, (32 * mt + (r & 3) + 8 * (r >> 2)) * rbz);
                     }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -361,7 +377,7 @@ __global__ __launch_bounds__(256, TRAIN ? BRIEF_TRAIN_WPE : 3) void k_fused(cons
             }
             write_image<NT>(Xs, hreg, wm, lane);
             STAMP(3)
-            __syncthreads();
+            lds_barrier();
             STAMP(4)
         }
         // ---- head (every wave evaluates it for its sample tile; F MACs per sample)
@@ -405,7 +421,7 @@ __global__ __launch_bounds__(256, TRAIN ? BRIEF_TRAIN_WPE : 3) void k_fused(cons
                     }
                 }
             }
-            __syncthreads();   // image is re-used by the next tile
+            lds_barrier();   // image is re-used by the next tile
             continue;
         }
         // ---- loss and dloss/dyhat (main.py:176-191)
@@ -431,7 +447,7 @@ __global__ __launch_bounds__(256, TRAIN ? BRIEF_TRAIN_WPE : 3) void k_fused(cons
         STAMP(5)
         // ---- head gradients: transpose own h tiles through LDS (scratch aliases the image: every
         //      wave must be past its head reads first), lane <-> local feature
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int t = 0; t < K::MTW; ++t) {
 #pragma unroll
@@ -439,7 +455,7 @@ __global__ __launch_bounds__(256, TRAIN ? BRIEF_TRAIN_WPE : 3) void k_fused(cons
         }
         if (hi == 0) *reinterpret_cast<float4 *>(Gw + ln * 4) = make_float4(g[0], g[1], g[2], g[3]);
         else *reinterpret_cast<float4 *>(Gw + 128 + ln * 4) = make_float4(x0, x1, x2, 1.0f);
-        __syncthreads();
+        lds_barrier();
         {
             float4 sW = make_float4(0.f, 0.f, 0.f, 0.f), sb = make_float4(0.f, 0.f, 0.f, 0.f);
             const float *trow = Tw + lane * 33;
@@ -484,14 +500,16 @@ __global__ __launch_bounds__(256, TRAIN ? BRIEF_TRAIN_WPE : 3) void k_fused(cons
             // stash delta_l for the weight-gradient GEMM and publish it as the B image
             const __amdgpu_buffer_rsrc_t rd =
                 __builtin_amdgcn_make_buffer_rsrc((void *)(a.D + (int64_t)(l - 1) * K::FP * npad), 0, stash_bytes, 0x00020000);
-            const int voff_s = (int)(n * 4) + hi * 4 * row_bytes;
+            int rbd = row_bytes;
+            asm volatile("" : "+s"(rbd));
+            const int voff_s = (int)(n * 4) + hi * 4 * rbd;
 #pragma unroll
             for (int t = 0; t < K::MTW; ++t) {
                 const int mt = wm + K::WM * t;
                 if (K::EXACT || mt < NT) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        bstore1(dl[t][r], rd, voff_s, (32 * mt + (r & 3) + 8 * (r >> 2)) * row_bytes);
+                        bstore1(dl[t][r], rd, voff_s, (32 * mt + (r & 3) + 8 * (r >> 2)) * rbd);
                 }
             }
             // z_{l-1} comes back from the stash while the chain runs (it is only needed after it)
@@ -504,13 +522,13 @@ __global__ __launch_bounds__(256, TRAIN ? BRIEF_TRAIN_WPE : 3) void k_fused(cons
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     zr[t][r] = 0.f;
-                    if (K::EXACT || mt < NT) zr[t][r] = bload1(rzp, voff_s, (32 * mt + (r & 3) + 8 * (r >> 2)) * row_bytes);
+                    if (K::EXACT || mt < NT) zr[t][r] = bload1(rzp, voff_s, (32 * mt + (r & 3) + 8 * (r >> 2)) * rbd);
                 }
             }
             STAMP(7)
-            __syncthreads();   // transpose scratch / previous chain finished with the image region
+            lds_barrier();   // transpose scratch / previous chain finished with the image region
             write_image<NT>(Xs, dl, wm, lane);
-            __syncthreads();
+            lds_barrier();
             STAMP(8)
 #pragma unroll
             for (int t = 0; t < K::MTW; ++t)
@@ -532,13 +550,13 @@ __global__ __launch_bounds__(256, TRAIN ? BRIEF_TRAIN_WPE : 3) void k_fused(cons
         }
         STAMP(7)
         // ---- first-layer gradients from delta_0 (lane <-> local feature)
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int t = 0; t < K::MTW; ++t) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) Tw[(32 * t + ROWMAP(r, hi)) * 33 + ln] = dl[t][r];
         }
-        __syncthreads();
+        lds_barrier();
         {
             float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f);
             const float *trow = Tw + lane * 33;
@@ -551,7 +569,7 @@ __global__ __launch_bounds__(256, TRAIN ? BRIEF_TRAIN_WPE : 3) void k_fused(cons
             }
             if (lane < 32 * K::MTW) { acc0[0] += s0.x; acc0[1] += s0.y; acc0[2] += s0.z; acc0[3] += s0.w; }
         }
-        __syncthreads();
+        lds_barrier();
         STAMP(6)
     }
 #undef FUSED_LOAD_BIAS
@@ -583,6 +601,8 @@ struct WgradArgs {
     int64_t npad;
     int nsplit;
     float *slabs;       // [(L-2)][nsplit][FP*FP + FP]
+    float *stamps;      // diagnostic build only: [blocks][8 waves][8]
+    int dbg;
 };
 
 template <int NT>
@@ -624,15 +644,25 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
     float4 ra[NLD], rb[NLD];
     // The loop body is branch-free: the prefetch of "chunk c+2" and the staging of "chunk c+1" are
     // clamped to the last chunk instead of being skipped (the redundant copies are never read).
+    // panel rows are npad*4 bytes apart: one fixed per-thread byte offset per staging pass, the chunk
+    // offset is a scalar (no per-load 64-bit address arithmetic on the VALU, which the f32 MFMA shares)
+    const int panel_bytes = (int)((int64_t)FP * a.npad * 4);
+    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void *)Dl, 0, panel_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc((void *)Zl, 0, panel_bytes, 0x00020000);
+    int voffs[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int e = tid + 512 * i;
+        voffs[i] = (e >> 3) * (int)(a.npad * 4) + (e & 7) * 16;
+    }
 #define WG_ISSUE(cc)                                                                              \
     _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                             \
         const int e = tid + 512 * i;                                                              \
         ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);                                                  \
         rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);                                                  \
         if (FULL || e < FP * 8) {                                                                 \
-            const int64_t off = (int64_t)(e >> 3) * a.npad + (cc) * 32 + (e & 7) * 4;             \
-            ra[i] = *reinterpret_cast<const float4 *>(Dl + off);                                  \
-            rb[i] = *reinterpret_cast<const float4 *>(Zl + off);                                  \
+            ra[i] = bload4(rsD, voffs[i], (int)((cc) * 128));                                     \
+            rb[i] = bload4(rsZ, voffs[i], (int)((cc) * 128));                                     \
         }                                                                                         \
     }
 #define WG_STAGE_A(buf, i)                                                                        \
@@ -658,12 +688,15 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
         const int64_t cn = c0 + 1 < c1 ? c0 + 1 : c1 - 1;
         WG_ISSUE(cn)
     }
-    __syncthreads();
+    lds_barrier();
+#ifdef BRIEF_STAMPS
+    float st_acc[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    long long st_last = clock64();
+#endif
     for (int64_t c = c0; c < c1; ++c) {
         const int cur = (int)(c - c0) & 1;
         const float *As = smem + cur * 2 * PANEL, *Bs = As + PANEL;
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) WG_STAGE_A(cur ^ 1, i)
+        STAMP(0)
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
             float4 af[TM], bf[TN];
@@ -672,7 +705,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
                 const int mt = wmk * TM + i;
                 af[i] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (MEX || mt < NT) af[i] = *reinterpret_cast<const float4 *>(As + (32 * mt + ln) * LDSW + 8 * gq + 4 * hi);
-                dbacc[i] += (af[i].x + af[i].y) + (af[i].z + af[i].w);
+                if (wnk == 0) dbacc[i] += (af[i].x + af[i].y) + (af[i].z + af[i].w);
             }
 #pragma unroll
             for (int jn = 0; jn < TN; ++jn) {
@@ -692,17 +725,26 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
                     }
                 }
             }
-            // a slice of the next chunk's staging rides in the shadow of this group's MFMAs
+            // The next chunk's staging rides in the shadow of the LAST two MFMA groups: its global loads were
+            // issued at the end of the previous iteration and get the barrier + two groups to land.
+            if (gq >= 2) {
 #pragma unroll
-            for (int i = 0; i < NLD; ++i)
-                if ((i & 3) == gq) WG_STAGE_B(cur ^ 1, i)
+                for (int i = 0; i < NLD; ++i)
+                    if ((i & 1) == (gq & 1)) { WG_STAGE_A(cur ^ 1, i) WG_STAGE_B(cur ^ 1, i) }
+            }
         }
+        STAMP(1)
         {
             const int64_t cn = c + 2 < c1 ? c + 2 : c1 - 1;
             WG_ISSUE(cn)
         }
-        __syncthreads();
+        STAMP(2)
+        lds_barrier();
+        STAMP(3)
     }
+#ifdef BRIEF_STAMPS
+    if (lane == 0 && a.stamps) for (int i = 0; i < 4; ++i) a.stamps[((int64_t)blockIdx.x * 8 + wave) * 8 + i] = st_acc[i];
+#endif
 #undef WG_ISSUE
 #undef WG_STAGE_A
 #undef WG_STAGE_B
@@ -1129,6 +1171,8 @@ int brief_siren_train_step(const brief_siren_desc *d, const float *packed, const
         WgradArgs wa;
         memset(&wa, 0, sizeof(wa));
         wa.d = *d; wa.Z = fa.Z; wa.D = fa.D; wa.npad = fa.npad; wa.nsplit = nsplit; wa.slabs = ws + wl.slabs;
+        wa.stamps = ws + wl.rec + (int64_t)kCUs * 4 * 4 * BRIEF_REC_FLOATS - 256 * 8 * 8;   // tail of the record region (diagnostics)
+        wa.dbg = fa.dbg;
         const int blocks = nsplit * (d->layers - 2);
 #define BRIEF_CASE(NTV)                                                                                    \
     case NTV:                                                                                              \

@@ -25,3 +25,11 @@ print('waves with stamps:', (tot > 0).sum(), 'mean total cycles/wave: %.0f' % to
 for i, nme in enumerate(names):
     v = st[tot > 0, i]
     print('%-36s mean %9.0f cycles  %5.1f%%   (min %9.0f max %9.0f)' % (nme, v.mean(), 100 * v.mean() / tot[tot > 0].mean(), v.min(), v.max()))
+# ---- wgrad stamps
+rec_floats = 256 * 4 * 4 * 528
+ws = m._ws[rec_off + rec_floats - 256 * 8 * 8: rec_off + rec_floats].view(256, 8, 8).cpu().numpy()
+w = ws[:255].reshape(-1, 8)[:, :4]
+tot = w.sum(1)
+print('wgrad: mean total cycles/wave %.0f (chunks per split ~36.8)' % tot.mean())
+for i, nme in enumerate(['stage A panel', 'MFMA groups (+B staging)', 'issue next loads', 'barrier']):
+    print('%-28s mean %9.0f  %5.1f%%  per chunk %7.0f' % (nme, w[:, i].mean(), 100 * w[:, i].mean() / tot.mean(), w[:, i].mean() / 36.8))
