@@ -964,6 +964,56 @@ __global__ void k_sse_u16(const uint16_t *__restrict__ x, const uint16_t *__rest
 
 __global__ void k_u64_to_double(const unsigned long long *acc, double *out) { *out = (double)*acc; }
 
+// ---------------------------------------------------------------------------------------------
+// block-boundary ("deblock") filter of the reference: deblock.py:7-78 (mode 1, Python float arithmetic,
+// pinned by goldens) / deblock.cpp:12-71,277-319 (mode 0, C integer arithmetic).  One launch filters one
+// boundary line for every slice z1..z2; a thread owns one position along the line and the 6 pixels
+// across it, so threads of a launch touch disjoint pixels.  Lines are launched in the reference's order
+// (the filter is in place and neighbouring lines overlap), see brief_pytorch_amd/deblock.py.
+__global__ void k_deblock_edge(uint16_t *img, int64_t H, int64_t W, int z1, int nz, int fixed, int a1, int na, int vertical,
+                               double alpha, double beta, double thres, int mode)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)nz * na) return;
+    const int z = z1 + (int)(t / na), pos = a1 + (int)(t % na);
+    const int64_t stride = vertical ? 1 : W;
+    uint16_t *p = img + (int64_t)z * H * W + (vertical ? (int64_t)pos * W + fixed : (int64_t)fixed * W + pos);
+    const int P2 = p[-3 * stride], P1 = p[-2 * stride], P0 = p[-stride], Q0 = p[0], Q1 = p[stride], Q2 = p[2 * stride];
+    if (mode == 1) {
+        const double p2 = P2, q2 = Q2;
+        double p1 = P1, p0 = P0, q0 = Q0, q1 = Q1;
+        if ((p1 + p0 + q0 + q1) / 4 > thres) return;
+        if (!(fabs(p0 - q0) < alpha && fabs(p1 - p0) < beta && fabs(q1 - q0) < beta)) return;
+        double delta0 = (4 * (q0 - p0) + (p1 - q1) + 4) / 8;
+        double deltap1 = (p2 + (p0 + q0 + 1) / 2 - 2 * p1) / 2;
+        double deltaq1 = (q2 + (q0 + p0 + 1) / 2 - 2 * q1) / 2;
+        double c1 = 20, c0 = c1;
+        if (fabs(p2 - p0) < beta) c0 += 1;
+        if (fabs(q2 - q0) < beta) c0 += 1;
+        delta0 = fmin(fmax(delta0, -c0), c0);
+        deltap1 = fmin(fmax(deltap1, -c1), c1);
+        deltaq1 = fmin(fmax(deltaq1, -c1), c1);
+        p1 += deltap1; p0 += delta0; q0 -= delta0; q1 += deltaq1;
+        p[-2 * stride] = (uint16_t)(long long)p1; p[-stride] = (uint16_t)(long long)p0;
+        p[0] = (uint16_t)(long long)q0; p[stride] = (uint16_t)(long long)q1;
+    } else {
+        if ((P1 + P0 + Q0 + Q1) / 4 > (int)thres) return;
+        const float al = (float)alpha, be = (float)beta;
+        if (!((float)abs(P0 - Q0) < al && (float)abs(P1 - P0) < be && (float)abs(Q1 - Q0) < be)) return;
+        float delta0 = (float)((4 * (Q0 - P0) + (P1 - Q1) + 4) / 8);
+        float deltap1 = (float)((P2 + (P0 + Q0 + 1) / 2 - 2 * P1) / 2);
+        float deltaq1 = (float)((Q2 + (Q0 + P0 + 1) / 2 - 2 * Q1) / 2);
+        float c1 = 20.f, c0 = 20.f;
+        if ((float)abs(P2 - P0) < be) c0 += 1.f;
+        if ((float)abs(Q2 - Q0) < be) c0 += 1.f;
+        delta0 = fminf(fmaxf(delta0, -c0), c0);
+        deltap1 = fminf(fmaxf(deltap1, -c1), c1);
+        deltaq1 = fminf(fmaxf(deltaq1, -c1), c1);
+        p[-2 * stride] = (uint16_t)(int)((float)P1 + deltap1); p[-stride] = (uint16_t)(int)((float)P0 + delta0);
+        p[0] = (uint16_t)(int)((float)Q0 - delta0); p[stride] = (uint16_t)(int)((float)Q1 + deltaq1);
+    }
+}
+
 // =============================================================================================
 // C-ABI
 static thread_local char g_err[512] = "";
@@ -1239,6 +1289,23 @@ int brief_profile_fused(double *total_ms, int64_t *launches)
     }
     *total_ms = tot;
     *launches = g_prof_n;
+    return 0;
+}
+
+int brief_deblock_edge(uint16_t *img, int64_t D, int64_t H, int64_t W, int z1, int z2, int fixed, int a1, int a2, int vertical,
+                       double index_a, double index_b, double thres, int mode, void *stream)
+{
+    if (!img || z1 < 0 || z2 >= D || z2 < z1 || a2 < a1 || a1 < 0) return fail(BRIEF_ERR_INVALID, "bad deblock edge");
+    const int64_t lim = vertical ? W : H, len = vertical ? H : W;
+    if (a2 >= len || fixed < 0 || fixed >= lim) return fail(BRIEF_ERR_INVALID, "deblock edge outside the volume");
+    if (fixed - 3 < 0 || fixed + 3 > lim - 1) return 0;      // deblock.py:57-63 / deblock.cpp:283-286: too close to the border
+    const double alpha = 0.8 * (pow(2.0, (mode == 0 ? (double)(float)index_a : index_a) / 6.0) - 1.0);
+    const double beta = 0.5 * (mode == 0 ? (double)(float)index_b : index_b) - 7.0;
+    const int nz = z2 - z1 + 1, na = a2 - a1 + 1;
+    const int64_t total = (int64_t)nz * na;
+    hipLaunchKernelGGL(k_deblock_edge, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, img, H, W, z1, nz,
+                       fixed, a1, na, vertical, alpha, beta, thres, mode);
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 

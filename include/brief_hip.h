@@ -105,6 +105,13 @@ int brief_sample_indices(int64_t *idx, int64_t n, int64_t pop, uint64_t seed, ui
 /* sum of squared differences of two integer volumes (for PSNR, utils/misc.py:451-456); sse_out: one double */
 int brief_sse_u16(const uint16_t *a, const uint16_t *b, int64_t n, double *sse_out, void *stream);
 
+/* Block-boundary filter of DivideTask outputs (reference deblock.py:52-78 / deblock.cpp:277-319): filters the
+ * boundary line  x == fixed, y in [a1,a2]  (vertical != 0)  or  y == fixed, x in [a1,a2]  (vertical == 0)  of
+ * every slice z1..z2 of a uint16 volume [D,H,W] in place.  mode 1 = deblock.py arithmetic, 0 = deblock.cpp
+ * arithmetic.  Lines must be issued in the reference's order (they overlap); see brief_pytorch_amd/deblock.py. */
+int brief_deblock_edge(uint16_t *img, int64_t D, int64_t H, int64_t W, int z1, int z2, int fixed, int a1, int a2, int vertical,
+                       double index_a, double index_b, double thres, int mode, void *stream);
+
 /* measurement hooks (bench.py): while enabled, every train step records a HIP event pair on the
  * caller's stream around its dominant kernel (the fused forward/loss/dgrad launch);
  * brief_profile_fused waits for them and returns the summed duration and the launch count. */

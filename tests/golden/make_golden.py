@@ -463,7 +463,58 @@ def g_divide():
     save("divide", **arrs)
 
 
+
+
+# ----------------------------------------------------------------------------- 9. deblock (reference deblock.py)
+def g_deblock():
+    """Runs the reference's Python deblocking filter (deblock.py: filter2d + its line enumeration) on a
+    small blocky volume.  deblock.cpp (integer arithmetic, needs libtiff headers) cannot be built here."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_deblock", os.path.join(REF, "deblock.py"))
+    rd = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rd)
+    rng = np.random.default_rng(21)
+    d, h, w = 6, 24, 32
+    base = make_volume((d, h, w), seed=48)[..., 0].astype(np.int64)
+    names = []
+    img = np.zeros((d, h, w), np.int64)
+    for (z1, z2) in ((0, 2), (3, 5)):
+        for (y1, y2) in ((0, 11), (12, 23)):
+            for (x1, x2) in ((0, 15), (16, 31)):
+                names.append("d_%d_%d-h_%d_%d-w_%d_%d" % (z1, z2, y1, y2, x1, x2))
+                img[z1:z2 + 1, y1:y2 + 1, x1:x2 + 1] = base[z1:z2 + 1, y1:y2 + 1, x1:x2 + 1] + rng.integers(-150, 150)
+    img = np.clip(img, 0, 65535).astype(np.uint16)[..., None]
+    out = img.copy()
+    lines = []
+    for block_info in names:                       # deblock.py:109-130 (3-D branch), explicit order
+        dd, hh, ww = block_info.split('-')
+        z1, z2 = (int(v) for v in dd.split('_')[1:])
+        x1, x2 = (int(v) for v in ww.split('_')[1:])
+        y1, y2 = (int(v) for v in hh.split('_')[1:])
+        l_flag = 1 if [z1, x1, y1, x1, y2] in lines else 0
+        r_flag = 1 if [z1, x2, y1, x2, y2] in lines else 0
+        d_flag = 1 if [z1, x1, y1, x2, y1] in lines else 0
+        u_flag = 1 if [z1, x1, y2, x2, y2] in lines else 0
+        for i in range(z1, z2 + 1):
+            if l_flag == 0:
+                lines.append([i, x1, y1, x1, y2])
+            if r_flag == 0:
+                lines.append([i, x2, y1, x2, y2])
+            if d_flag == 0:
+                lines.append([i, x1, y1, x2, y1])
+            if u_flag == 0:
+                lines.append([i, x1, y2, x2, y2])
+    for k in range(out.shape[-1]):
+        for p in lines:
+            out[p[0], :, :, k] = rd.filter2d(p[1:], out[p[0], :, :, k], 51, 2000, 65535)
+    # a second run with a brightness threshold that disables part of the volume and a tighter beta
+    out2 = img.copy()
+    for p in lines:
+        out2[p[0], :, :, 0] = rd.filter2d(p[1:], out2[p[0], :, :, 0], 48, 700, 20050)
+    save("deblock", img=img, names=np.array(names), lines=np.array(lines), out=out, out2=out2)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["init", "forward", "grads", "optim", "trace", "decode", "budget", "divide"]
+    which = sys.argv[1:] or ["init", "forward", "grads", "optim", "trace", "decode", "budget", "divide", "deblock"]
     for w in which:
         globals()["g_" + w]()

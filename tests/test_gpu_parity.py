@@ -258,3 +258,29 @@ def test_errors_are_loud():
     m, _, _ = make_net(3, 16, 20.0)
     with pytest.raises(_lib.BriefError):
         m.train_step(10, torch.zeros(10, 1, device=DEV), coords=None, grid=((4, 4), -1.0, 1.0))   # ndim != cin
+
+
+def test_deblock_vs_oracle_and_golden(golden):
+    from brief_pytorch_amd.deblock import block_edges, deblock_volume
+    g = golden("deblock")
+    names = [str(n) for n in g["names"]]
+    assert sum((e[1] - e[0] + 1) for e in block_edges(names)) == len(g["lines"])
+    t = torch.from_numpy(g["img"].copy()).to(DEV)
+    assert np.array_equal(deblock_volume(t, names).cpu().numpy(), g["out"])                 # reference deblock.py, bit-exact
+    t2 = torch.from_numpy(g["img"].copy()).to(DEV)
+    assert np.array_equal(deblock_volume(t2, names, 48, 700, 20050).cpu().numpy(), g["out2"])
+    # larger volume, both arithmetic flavours against the oracle
+    from brief_pytorch_amd.misc import divide_data
+    from brief_pytorch_amd.synthetic import make_volume
+    vol = make_volume((20, 96, 128), seed=8)
+    rng = np.random.default_rng(2)
+    chunks, _ = divide_data(vol, "total_2_3_4")
+    blocky = vol.astype(np.int64)
+    for c in chunks:
+        r = c["d"], c["h"], c["w"]
+        blocky[r[0][0]:r[0][1] + 1, r[1][0]:r[1][1] + 1, r[2][0]:r[2][1] + 1] += rng.integers(-200, 200)
+    blocky = np.clip(blocky, 0, 65535).astype(np.uint16)
+    bn = [c["name"] for c in chunks]
+    for mode in (1, 0):
+        tt = torch.from_numpy(blocky.copy()).to(DEV)
+        assert np.array_equal(deblock_volume(tt, bn, mode=mode).cpu().numpy(), O.deblock(blocky, bn, mode=mode)), mode

@@ -170,3 +170,14 @@ def test_decode_and_metrics(golden):
     assert abs(O.ssim(g["pair_a"].astype(np.float32), g["pair_b"].astype(np.float32), 65535) - g["pair_ssim"][0]) < 1e-5
     assert abs(O.psnr(g["img_a"], g["img_b"], 255) - g["img_psnr"][0]) < 1e-4
     assert abs(O.ssim(g["img_a"].astype(np.float32), g["img_b"].astype(np.float32), 255) - g["img_ssim"][0]) < 1e-5
+
+
+def test_deblock_oracle_vs_reference_python(golden):
+    g = golden("deblock")
+    names = [str(n) for n in g["names"]]
+    assert O.deblock_lines(names) == g["lines"].tolist()
+    assert np.array_equal(O.deblock(g["img"], names), g["out"])
+    assert np.array_equal(O.deblock(g["img"], names, 48, 700, 20050), g["out2"])
+    # the C++ flavour (integer arithmetic) is a different filter: it must differ somewhere, not everywhere
+    oc = O.deblock(g["img"], names, mode=0)
+    assert 0 < (oc != g["out"]).sum() < 0.2 * (g["img"] != g["out"]).sum()
