@@ -38,7 +38,7 @@ OPT_KIND = {"Adamax": 0, "Adam": 1, "SGD": 2}
 OUT_F32, OUT_U8, OUT_U16 = 0, 1, 2
 
 EXPORTS = ["brief_version", "brief_last_error", "brief_param_count", "brief_packed_count",
-           "brief_train_workspace_bytes", "brief_siren_repack", "brief_siren_forward", "brief_siren_train_step",
+           "brief_train_workspace_bytes", "brief_siren_repack", "brief_siren_forward", "brief_siren_train_step", "brief_siren_fit_step",
            "brief_optim_step", "brief_sample_indices", "brief_sse_u16", "brief_profile_enable", "brief_profile_fused", "brief_deblock_edge"]
 
 
@@ -88,6 +88,8 @@ def lib():
     L.brief_siren_repack.argtypes = [dp, vp, vp, vp]
     L.brief_siren_forward.argtypes = [dp, vp, gp, bp, vp, C.c_int, C.c_float, C.c_float, C.c_double, C.c_double, vp]
     L.brief_siren_train_step.argtypes = [dp, vp, gp, bp, C.c_int, C.c_float, C.c_float, vp, vp, vp, vp, C.c_int64, vp]
+    L.brief_siren_fit_step.argtypes = [dp, vp, vp, gp, bp, C.c_int, C.c_float, C.c_float, C.c_int, vp, vp,
+                                       C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64, vp, vp, vp, C.c_int64, vp]
     L.brief_optim_step.argtypes = [C.c_int, vp, vp, vp, vp, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64, vp]
     L.brief_sample_indices.argtypes = [vp, C.c_int64, C.c_int64, C.c_uint64, C.c_uint64, vp]
     L.brief_sse_u16.argtypes = [vp, vp, C.c_int64, vp, vp]

@@ -771,6 +771,41 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
+// optimizer: same arithmetic, in the same order, as oracle_optim_step (torch single-tensor rules)
+struct OptimScalars { int kind; float w1, fb2, w2, feps, nstep, bc2s; };
+
+__device__ __forceinline__ float optim_apply(const OptimScalars &o, float gi, float *__restrict__ p, float *__restrict__ s1,
+                                             float *__restrict__ s2, int64_t i)
+{
+    const int kind = o.kind;
+    const float w1 = o.w1, fb2 = o.fb2, w2 = o.w2, feps = o.feps, nstep = o.nstep, bc2s = o.bc2s;
+    if (kind == BRIEF_OPT_ADAMAX) {
+        const float m = __fmaf_rn(w1, __fsub_rn(gi, s1[i]), s1[i]);
+        const float ua = __fmul_rn(s2[i], fb2), ub = __fadd_rn(fabsf(gi), feps);
+        const float u = ua > ub ? ua : ub;
+        s1[i] = m; s2[i] = u;
+        p[i] = __fadd_rn(p[i], __fdiv_rn(__fmul_rn(nstep, m), u));
+    } else if (kind == BRIEF_OPT_ADAM) {
+        const float m = __fmaf_rn(w1, __fsub_rn(gi, s1[i]), s1[i]);
+        const float v = __fadd_rn(__fmul_rn(s2[i], fb2), __fmul_rn(w2, __fmul_rn(gi, gi)));
+        s1[i] = m; s2[i] = v;
+        const float den = __fadd_rn(__fdiv_rn(sqrtf(v), bc2s), feps);   // sqrtf: correctly rounded (hipcc default)
+        p[i] = __fadd_rn(p[i], __fdiv_rn(__fmul_rn(nstep, m), den));
+    } else {
+        p[i] = __fadd_rn(p[i], __fmul_rn(nstep, gi));
+    }
+    return p[i];
+}
+
+__global__ void k_optim(OptimScalars o, float *__restrict__ p, const float *__restrict__ g, float *__restrict__ s1,
+                        float *__restrict__ s2, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    optim_apply(o, g[i], p, s1, s2, i);
+}
+
+// ---------------------------------------------------------------------------------------------
 // deterministic reduction of the partials into the canonical gradient buffer
 struct ReduceArgs {
     brief_siren_desc d;
@@ -781,7 +816,19 @@ struct ReduceArgs {
     float *grads;
     float *loss_out;
     float inv_count;
+    // optional fused optimizer step + scatter into the fragment-ordered copies (brief_siren_fit_step)
+    int update;
+    OptimScalars opt;
+    float *params, *s1, *s2, *pk;
 };
+
+// where a hidden-layer weight W_l[o][i] lives in the A-fragment orders (see brief_layout.h)
+__device__ __forceinline__ int64_t frag_index(int NT, int row, int col)
+{
+    const int mt = row >> 5, ii = row & 31, kt = col >> 5, rem = col & 31;
+    const int q = rem >> 3, hi = (rem >> 2) & 1, j = rem & 3;
+    return ((((int64_t)mt * NT + kt) * 4 + q) * 64 + 32 * hi + ii) * 4 + j;
+}
 
 // blocks [0, nb_hidden): one thread per hidden-layer parameter, nsplit slab terms each.
 // blocks [nb_hidden, ...): one WAVE per first-layer / head parameter (and one for the loss): these sum
@@ -809,6 +856,17 @@ __global__ __launch_bounds__(256) void k_reduce(const ReduceArgs a, int nb_hidde
 #pragma unroll 8
         for (int sp = 0; sp < a.nsplit; ++sp) s += base[(int64_t)sp * slab_sz];
         a.grads[l0_count + hidx] = s;
+        if (a.update) {
+            const float pv = optim_apply(a.opt, s, a.params, a.s1, a.s2, l0_count + hidx);
+            float *blk = a.pk + brief_pk_hidden(d, l);
+            if (r < (int64_t)F * F) {
+                const int o = (int)(r / F), i = (int)(r % F);
+                blk[frag_index(NT, o, i)] = pv;                               // A-fragments of W
+                blk[(int64_t)FP * FP + frag_index(NT, i, o)] = pv;            // A-fragments of W^T
+            } else {
+                blk[2 * (int64_t)FP * FP + (r - (int64_t)F * F)] = pv;        // bias
+            }
+        }
         return;
     }
     // ---- skinny parameters: wave w of this block handles item (blockIdx - nb_hidden)*4 + w
@@ -844,35 +902,21 @@ __global__ __launch_bounds__(256) void k_reduce(const ReduceArgs a, int nb_hidde
     }
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
     if (lane == 0) {
-        if (item == l0_count + head_count) *a.loss_out = s * a.inv_count;
-        else if (item < l0_count) a.grads[item] = s;
-        else a.grads[off_head + (item - l0_count)] = s;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// optimizer: same arithmetic, in the same order, as oracle_optim_step (torch single-tensor rules)
-__global__ void k_optim(int kind, float *__restrict__ p, const float *__restrict__ g, float *__restrict__ s1,
-                        float *__restrict__ s2, int64_t n, float w1, float fb2, float w2, float feps,
-                        float nstep, float bc2s)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float gi = g[i];
-    if (kind == BRIEF_OPT_ADAMAX) {
-        const float m = __fmaf_rn(w1, __fsub_rn(gi, s1[i]), s1[i]);
-        const float ua = __fmul_rn(s2[i], fb2), ub = __fadd_rn(fabsf(gi), feps);
-        const float u = ua > ub ? ua : ub;
-        s1[i] = m; s2[i] = u;
-        p[i] = __fadd_rn(p[i], __fdiv_rn(__fmul_rn(nstep, m), u));
-    } else if (kind == BRIEF_OPT_ADAM) {
-        const float m = __fmaf_rn(w1, __fsub_rn(gi, s1[i]), s1[i]);
-        const float v = __fadd_rn(__fmul_rn(s2[i], fb2), __fmul_rn(w2, __fmul_rn(gi, gi)));
-        s1[i] = m; s2[i] = v;
-        const float den = __fadd_rn(__fdiv_rn(sqrtf(v), bc2s), feps);   // sqrtf: correctly rounded (hipcc default)
-        p[i] = __fadd_rn(p[i], __fdiv_rn(__fmul_rn(nstep, m), den));
-    } else {
-        p[i] = __fadd_rn(p[i], __fmul_rn(nstep, gi));
+        if (item == l0_count + head_count) { *a.loss_out = s * a.inv_count; return; }
+        const int64_t e = item < l0_count ? item : off_head + (item - l0_count);
+        a.grads[e] = s;
+        if (a.update) {
+            const float pv = optim_apply(a.opt, s, a.params, a.s1, a.s2, e);
+            if (item < l0_count) {
+                if (item < (int64_t)F * cin) a.pk[(item / cin) * 4 + (item % cin)] = pv;     // W0p[o][c]
+                else a.pk[(item - (int64_t)F * cin) * 4 + 3] = pv;                           // W0p[o][3] = bias
+            } else {
+                const int64_t r = item - l0_count;
+                float *hp = a.pk + brief_pk_head(d);
+                if (r < (int64_t)cout * F) hp[(r / F) * FP + (r % F)] = pv;                   // Whp[c][f]
+                else hp[4 * (int64_t)FP + (r - (int64_t)cout * F)] = pv;                      // bhp[c]
+            }
+        }
     }
 }
 
@@ -1051,6 +1095,17 @@ static const int kMaxFusedGrid = 512;   // 2 resident workgroups per CU on 256 C
 static const int kWgradBlocks = 256;
 
 // persistent grid: g_wg_per_cu workgroups per CU, each walking tiles blockIdx, blockIdx+grid, ...
+// scalars prepared in double exactly as oracle_optim_step / torch do
+static OptimScalars optim_scalars(int kind, double lr, double beta1, double beta2, double eps, int64_t t)
+{
+    OptimScalars o;
+    o.kind = kind;
+    o.w1 = (float)(1.0 - beta1); o.fb2 = (float)beta2; o.w2 = (float)(1.0 - beta2); o.feps = (float)eps;
+    o.nstep = kind == BRIEF_OPT_SGD ? (float)(-lr) : (float)(-(lr / (1.0 - pow(beta1, (double)t))));
+    o.bc2s = kind == BRIEF_OPT_ADAM ? (float)sqrt(1.0 - pow(beta2, (double)t)) : 1.f;
+    return o;
+}
+
 static const int kCUs = 256;            // MI355X
 static int g_wg_per_cu = BRIEF_TRAIN_WPE;   // resident k_fused<TRAIN> workgroups per CU
 static int g_stagger = 1;               // start delay per residency slot, units of s_sleep(127)
@@ -1181,10 +1236,14 @@ int brief_siren_forward(const brief_siren_desc *d, const float *packed, const br
     return launch_fused<false>(fa, fused_grid(*d, batch->n, false), (hipStream_t)stream);
 }
 
-int brief_siren_train_step(const brief_siren_desc *d, const float *packed, const brief_grid_desc *grid,
+struct UpdatePayload { OptimScalars opt; float *params, *s1, *s2, *pk; };
+
+}   // extern "C"
+
+static int train_step_impl(const brief_siren_desc *d, const float *packed, const brief_grid_desc *grid,
                            const brief_batch_desc *batch, int loss_kind, float thr, float beta,
                            float *grads, float *loss_out, float *yhat_out,
-                           void *workspace, int64_t workspace_bytes, void *stream)
+                           void *workspace, int64_t workspace_bytes, void *stream, const UpdatePayload *upd)
 {
     if (int rc = check_desc(d)) return rc;
     if (int rc = check_batch(d, grid, batch, true)) return rc;
@@ -1239,6 +1298,7 @@ int brief_siren_train_step(const brief_siren_desc *d, const float *packed, const
     memset(&ra, 0, sizeof(ra));
     ra.d = *d; ra.rec = fa.rec; ra.nrec_wg = grid1; ra.slabs = ws + wl.slabs; ra.nsplit = nsplit;
     ra.grads = grads; ra.loss_out = loss_out; ra.inv_count = inv_count;
+    if (upd) { ra.update = 1; ra.opt = upd->opt; ra.params = upd->params; ra.s1 = upd->s1; ra.s2 = upd->s2; ra.pk = upd->pk; }
     const int64_t l0_count = (int64_t)d->features * d->cin + d->features;
     const int64_t hcount = brief_canon_head_off(*d) - l0_count;
     const int64_t skinny = l0_count + (int64_t)d->cout * d->features + d->cout + 1;   // + the loss
@@ -1249,19 +1309,40 @@ int brief_siren_train_step(const brief_siren_desc *d, const float *packed, const
     return 0;
 }
 
+extern "C" {
+
+int brief_siren_train_step(const brief_siren_desc *d, const float *packed, const brief_grid_desc *grid,
+                           const brief_batch_desc *batch, int loss_kind, float thr, float beta,
+                           float *grads, float *loss_out, float *yhat_out,
+                           void *workspace, int64_t workspace_bytes, void *stream)
+{
+    return train_step_impl(d, packed, grid, batch, loss_kind, thr, beta, grads, loss_out, yhat_out, workspace, workspace_bytes,
+                           stream, nullptr);
+}
+
+int brief_siren_fit_step(const brief_siren_desc *d, float *params, float *packed, const brief_grid_desc *grid,
+                         const brief_batch_desc *batch, int loss_kind, float thr, float beta,
+                         int optim_kind, float *state1, float *state2, double lr, double beta1, double beta2, double eps, int64_t t,
+                         float *grads, float *loss_out, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    if (optim_kind < BRIEF_OPT_ADAMAX || optim_kind > BRIEF_OPT_SGD) return fail(BRIEF_ERR_INVALID, "bad optimizer kind");
+    if (!params || t < 1) return fail(BRIEF_ERR_INVALID, "bad optimizer arguments");
+    if (optim_kind != BRIEF_OPT_SGD && (!state1 || !state2)) return fail(BRIEF_ERR_INVALID, "optimizer state required");
+    UpdatePayload up;
+    up.opt = optim_scalars(optim_kind, lr, beta1, beta2, eps, t);
+    up.params = params; up.s1 = state1; up.s2 = state2; up.pk = packed;
+    return train_step_impl(d, packed, grid, batch, loss_kind, thr, beta, grads, loss_out, nullptr, workspace, workspace_bytes, stream, &up);
+}
+
 int brief_optim_step(int kind, float *params, const float *grads, float *state1, float *state2, int64_t count,
                      double lr, double beta1, double beta2, double eps, int64_t t, void *stream)
 {
     if (kind < BRIEF_OPT_ADAMAX || kind > BRIEF_OPT_SGD) return fail(BRIEF_ERR_INVALID, "bad optimizer kind");
     if (!params || !grads || count < 1 || t < 1) return fail(BRIEF_ERR_INVALID, "bad optimizer arguments");
     if (kind != BRIEF_OPT_SGD && (!state1 || !state2)) return fail(BRIEF_ERR_INVALID, "optimizer state required");
-    // scalars prepared in double exactly as oracle_optim_step / torch do
-    float nstep, bc2s = 1.f;
-    if (kind == BRIEF_OPT_SGD) nstep = (float)(-lr);
-    else nstep = (float)(-(lr / (1.0 - pow(beta1, (double)t))));
-    if (kind == BRIEF_OPT_ADAM) bc2s = (float)sqrt(1.0 - pow(beta2, (double)t));
-    hipLaunchKernelGGL(k_optim, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, kind, params, grads,
-                       state1, state2, count, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, nstep, bc2s);
+    const OptimScalars os = optim_scalars(kind, lr, beta1, beta2, eps, t);
+    hipLaunchKernelGGL(k_optim, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, os, params, grads,
+                       state1, state2, count);
     HIP_TRY(hipGetLastError());
     return 0;
 }

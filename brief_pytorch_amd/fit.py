@@ -74,11 +74,5 @@ class Fitter:
             else:
                 _lib.check(L.brief_sample_indices(_lib.ptr(self.idx), self.n, self.pop, self.seed, t, _lib.stream_ptr()))
                 idx = self.idx
-        loss, _ = self.m.train_step(self.n, self.targets, idx=idx, weights=self.weights,
-                                    grid=(self.dims, self.range[0], self.range[1]),
-                                    loss=self.loss_name, thr=self.thr, beta=self.beta)
-        _lib.check(L.brief_optim_step(self.opt, _lib.ptr(self.m.params), _lib.ptr(self.m.grads), _lib.ptr(self.s1), _lib.ptr(self.s2),
-                                      self.m.params.numel(), self.lr_at(t), 0.9, 0.999, 1e-8, t, _lib.stream_ptr()))
-        self.m._stale = True
-        self.m.sync_packed()
-        return loss
+        return self.m.fit_step(self.n, self.targets, self.opt, self.s1, self.s2, self.lr_at(t), t, idx=idx, weights=self.weights,
+                               grid=(self.dims, self.range[0], self.range[1]), loss=self.loss_name, thr=self.thr, beta=self.beta)

@@ -282,6 +282,32 @@ class SIREN:
             _lib.ptr(self._ws), self._ws.numel() * 4, _lib.stream_ptr()))
         return self._loss, yhat
 
+    def fit_step(self, n, targets, opt_kind, s1, s2, lr, t, idx=None, weights=None, grid=None, offset=0,
+                 loss="datal2", thr=0.0, beta=0.01, betas=(0.9, 0.999), eps=1e-8):
+        """train_step + optimizer update + refresh of the packed copy in one C-ABI call (three launches);
+        bit-identical to the separate calls.  Returns the device loss tensor."""
+        self._require_gpu()
+        self.sync_packed()
+        dev = self.params.device
+        if self.grads is None:
+            self.grads = torch.zeros_like(self.params)
+            self._loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        need = _lib.lib().brief_train_workspace_bytes(C.byref(self.desc), int(n))
+        if need < 0:
+            raise _lib.BriefError(_lib.lib().brief_last_error().decode())
+        if self._ws is None or self._ws.numel() * 4 < need:
+            self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev)
+        dims, lo, hi = grid
+        g = self._grid(dims, lo, hi)
+        b = _lib.BatchDesc(None, targets.data_ptr(), weights.data_ptr() if weights is not None else None,
+                           idx.data_ptr() if idx is not None else None, int(offset), int(n))
+        _lib.check(_lib.lib().brief_siren_fit_step(
+            C.byref(self.desc), _lib.ptr(self.params), _lib.ptr(self.packed), C.byref(g), C.byref(b),
+            _lib.LOSS_KIND[loss], float(thr), float(beta), int(opt_kind), _lib.ptr(s1), _lib.ptr(s2),
+            float(lr), betas[0], betas[1], eps, int(t), _lib.ptr(self.grads), _lib.ptr(self._loss),
+            _lib.ptr(self._ws), self._ws.numel() * 4, _lib.stream_ptr()))
+        return self._loss
+
     # ---- budget -> width (utils/Networks.py:291-314)
     @staticmethod
     def calc_param_count(coords_channel, data_channel, features, layers, res=False, **kwargs):

@@ -93,6 +93,15 @@ int brief_siren_train_step(const brief_siren_desc *d, const float *packed, const
                            float *grads, float *loss_out, float *yhat_out,
                            void *workspace, int64_t workspace_bytes, void *stream);
 
+/* One whole iteration of the loop body main.py:385-400 in three launches: brief_siren_train_step followed by the
+ * optimizer update of brief_optim_step, with the update applied inside the gradient reduction and written through
+ * to BOTH the canonical `params` and the fragment-ordered `packed` copy (no separate repack).  `packed` must hold
+ * a repack of `params` on entry.  Results are bit-identical to train_step + optim_step + repack. */
+int brief_siren_fit_step(const brief_siren_desc *d, float *params, float *packed, const brief_grid_desc *grid,
+                         const brief_batch_desc *batch, int loss_kind, float thr, float beta,
+                         int optim_kind, float *state1, float *state2, double lr, double beta1, double beta2, double eps, int64_t t,
+                         float *grads, float *loss_out, void *workspace, int64_t workspace_bytes, void *stream);
+
 /* optimizer.step() of main.py:399 (torch.optim.Adamax/Adam/SGD single-tensor rules); t is the
  * 1-based step count, lr the scheduler's current value.  state1/state2: exp_avg / exp_inf|exp_avg_sq. */
 int brief_optim_step(int kind, float *params, const float *grads, float *state1, float *state2, int64_t count,

@@ -284,3 +284,30 @@ def test_deblock_vs_oracle_and_golden(golden):
     for mode in (1, 0):
         tt = torch.from_numpy(blocky.copy()).to(DEV)
         assert np.array_equal(deblock_volume(tt, bn, mode=mode).cpu().numpy(), O.deblock(blocky, bn, mode=mode)), mode
+
+
+@pytest.mark.parametrize("L,F,name", [(5, 256, "Adamax"), (4, 40, "Adam"), (3, 96, "SGD"), (2, 20, "Adamax")])
+def test_fit_step_equals_separate_calls(L, F, name):
+    """brief_siren_fit_step (reduce + optimizer + packed write-through fused) is bit-identical to
+    train_step + optim_step + repack, parameters AND the fragment-ordered copy."""
+    n = 5000
+    rng = np.random.default_rng(L + F)
+    dims = (20, 25, 30)
+    tv = torch.from_numpy(rng.uniform(0, 100, size=(int(np.prod(dims)), 1)).astype(np.float32)).to(DEV)
+    idxs = [torch.from_numpy(rng.integers(0, int(np.prod(dims)), size=n)).to(DEV) for _ in range(3)]
+    ma, _, _ = make_net(L, F, 20.0, seed=77)
+    mb, _, _ = make_net(L, F, 20.0, seed=77)
+    kind = _lib.OPT_KIND[name]
+    sa1, sa2 = torch.zeros_like(ma.params), torch.zeros_like(ma.params)
+    sb1, sb2 = torch.zeros_like(mb.params), torch.zeros_like(mb.params)
+    for t in range(1, 4):
+        la, _ = ma.train_step(n, tv, idx=idxs[t - 1], grid=(dims, -1.0, 1.0))
+        la = la.clone()
+        _lib.check(_lib.lib().brief_optim_step(kind, _lib.ptr(ma.params), _lib.ptr(ma.grads), _lib.ptr(sa1), _lib.ptr(sa2),
+                                               ma.params.numel(), 1e-3, 0.9, 0.999, 1e-8, t, _lib.stream_ptr()))
+        ma._stale = True
+        ma.sync_packed()
+        lb = mb.fit_step(n, tv, kind, sb1, sb2, 1e-3, t, idx=idxs[t - 1], grid=(dims, -1.0, 1.0))
+        assert torch.equal(la, lb) and torch.equal(ma.grads, mb.grads)
+        assert torch.equal(ma.params, mb.params) and torch.equal(sa1, sb1) and torch.equal(sa2, sb2)
+        assert torch.equal(ma.packed, mb.packed)
