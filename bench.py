@@ -140,6 +140,14 @@ def main():
         psnr = float(-10.0 * np.log10(sse.item() / cnt.item() / 65535.0 ** 2))
 
     if rank == 0:
+        # HBM traffic of the dominant kernel: PMC counters need rocprofv3, so the figure comes from the committed
+        # counter passes of this same command (profiles/r01_traffic.json: 2*FETCH_SIZE + WRITE_SIZE, per launch)
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+                traffic = float(json.load(f)["k_fused"]["hbm_bytes"])
+        except Exception:
+            pass
         train_f, fused_f, _ = flops_per_sample(LAYERS, FEATURES)
         fused_ms = tot_ms.value / max(launches.value, 1)
         achieved = fused_f * SAMPLE / (fused_ms * 1e-3) / 1e12
@@ -156,7 +164,7 @@ def main():
                        "params": net.param_count, "bits_per_voxel": 32.0 * net.param_count / float(np.prod(BLOCK))},
             "roofline": {"bound": "mfma", "kernel": "k_fused<8,true> (forward+loss+dgrad)", "achieved": achieved,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": None, "kernel_ms": fused_ms, "flop_per_launch": fused_f * SAMPLE,
+                         "traffic": traffic, "kernel_ms": fused_ms, "flop_per_launch": fused_f * SAMPLE,
                          "step_tflops": train_f * SAMPLE / (ms_step * 1e-3) / 1e12,
                          "step_frac": train_f * SAMPLE / (ms_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS},
             "loss": float(loss.item()), "psnr_db": psnr, "psnr_after_steps": args.steps + args.warmup,

@@ -30,7 +30,7 @@ class GridDesc(C.Structure):
 
 class BatchDesc(C.Structure):
     _fields_ = [("coords", C.c_void_p), ("targets", C.c_void_p), ("weights", C.c_void_p), ("idx", C.c_void_p),
-                ("offset", C.c_int64), ("n", C.c_int64)]
+                ("offset", C.c_int64), ("n", C.c_int64), ("rng_pop", C.c_int64), ("rng_seed", C.c_uint64), ("rng_step", C.c_uint64)]
 
 
 LOSS_KIND = {"datal2": 0, "datasmoothl1": 1}

@@ -66,6 +66,7 @@ struct FusedArgs {
     const int64_t *idx;
     int64_t offset;
     int64_t n;
+    uint64_t rng_pop, rng_seed, rng_step;   // idx == NULL && rng_pop > 0: sample j in-kernel (Philox)
     GridArgs grid;
     int loss_kind;
     float thr, beta, inv_count;
@@ -183,6 +184,29 @@ __device__ __forceinline__ void write_image(float4 *Xs, const f32x16 (&h)[KCfg<N
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 voxel-index stream (stands in for the CPU torch.randint of main.py:156)
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1)
+{
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+__device__ __forceinline__ int64_t philox_index(int64_t i, uint64_t pop, uint64_t seed, uint64_t step)
+{
+    uint32_t c[4] = {(uint32_t)i, (uint32_t)((uint64_t)i >> 32), (uint32_t)step, (uint32_t)(step >> 32)};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const uint64_t r64 = ((uint64_t)c[0] << 32) | c[1];
+    return (int64_t)__umul64hi(r64, pop);      // multiply-shift: bias < pop / 2^64
+}
+
 // LDS map of k_fused (floats):  R = max(image, transpose scratch) | G (per-wave g / coords) | HW (head weights)
 //   image  X : WS x NT x 1024            activation register image(s)
 //   scratch T: 4 waves x 64 x 33          per-wave [feature][sample] transpose (aliases X: used only while
@@ -265,7 +289,7 @@ __global__ __launch_bounds__(256, TRAIN ? BRIEF_TRAIN_WPE : 3) void k_fused(cons
         // ---- sample inputs (every wave of the sample tile fetches them; they are tiny).  Targets and
         //      weights are fetched now although the loss needs them a whole forward pass later.
         int64_t j = 0;
-        if (valid) j = a.idx ? a.idx[n] : n + a.offset;
+        if (valid) j = a.idx ? a.idx[n] : (a.rng_pop ? philox_index(n, a.rng_pop, a.rng_seed, a.rng_step) : n + a.offset);
         float x0 = 0.f, x1 = 0.f, x2 = 0.f;
         float yv[4] = {0.f, 0.f, 0.f, 0.f}, wv4[4] = {1.f, 1.f, 1.f, 1.f};
         if (valid) {
@@ -969,30 +993,10 @@ __global__ void k_repack(const brief_siren_desc d, const float *__restrict__ par
     pk[e] = v;
 }
 
-// ---------------------------------------------------------------------------------------------
-// Philox4x32-10 voxel-index stream (stands in for the CPU torch.randint of main.py:156)
-__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1)
-{
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
-    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-}
-
 __global__ void k_sample(int64_t *idx, int64_t n, uint64_t pop, uint64_t seed, uint64_t step)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t c[4] = {(uint32_t)i, (uint32_t)((uint64_t)i >> 32), (uint32_t)step, (uint32_t)(step >> 32)};
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        philox_round(c, k0, k1);
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    const uint64_t r64 = ((uint64_t)c[0] << 32) | c[1];
-    // unbiased enough for pop << 2^64 (multiply-shift); pop <= 2^40 here
-    idx[i] = (int64_t)__umul64hi(r64, pop);
+    if (i < n) idx[i] = philox_index(i, pop, seed, step);
 }
 
 __global__ void k_sse_u16(const uint16_t *__restrict__ x, const uint16_t *__restrict__ y, int64_t n, unsigned long long *acc)
@@ -1265,6 +1269,7 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
     fa.d = *d; fa.pk = packed;
     fa.coords = batch->coords; fa.targets = batch->targets; fa.weights = batch->weights;
     fa.idx = batch->idx; fa.offset = batch->offset; fa.n = batch->n;
+    if (!batch->idx && batch->rng_pop > 0) { fa.rng_pop = (uint64_t)batch->rng_pop; fa.rng_seed = batch->rng_seed; fa.rng_step = batch->rng_step; }
     fill_grid(fa.grid, grid);
     fa.loss_kind = loss_kind; fa.thr = thr; fa.beta = beta; fa.inv_count = inv_count;
     fa.Z = ws + wl.z; fa.D = ws + wl.dd; fa.npad = brief_npad(nt, batch->n);

@@ -50,7 +50,6 @@ class Fitter:
         dev = module.params.device
         self.s1 = torch.zeros_like(module.params)
         self.s2 = torch.zeros_like(module.params)
-        self.idx = torch.empty(self.n, dtype=torch.int64, device=dev) if sampler == "randompoint" else None
         sch = scheduler or {"name": "none"}
         if sch.get("name") == "MultiStepLR":
             self.lr_at = multistep_lr(lr, sch.get("milestones", []), sch.get("gamma", 0.1))
@@ -66,13 +65,12 @@ class Fitter:
     def step(self):
         """one optimisation step; returns the device loss tensor (no sync)."""
         self.t += 1
-        t, L = self.t, _lib.lib()
-        idx = None
+        t = self.t
+        idx, rng = None, None
         if self.sampler == "randompoint":
             if self.index_stream is not None:
                 idx = self.index_stream(t)
             else:
-                _lib.check(L.brief_sample_indices(_lib.ptr(self.idx), self.n, self.pop, self.seed, t, _lib.stream_ptr()))
-                idx = self.idx
+                rng = (self.pop, self.seed, t)      # drawn inside the fused kernel (== brief_sample_indices(pop, seed, t))
         return self.m.fit_step(self.n, self.targets, self.opt, self.s1, self.s2, self.lr_at(t), t, idx=idx, weights=self.weights,
-                               grid=(self.dims, self.range[0], self.range[1]), loss=self.loss_name, thr=self.thr, beta=self.beta)
+                               grid=(self.dims, self.range[0], self.range[1]), loss=self.loss_name, thr=self.thr, beta=self.beta, rng=rng)

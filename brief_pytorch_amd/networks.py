@@ -226,7 +226,7 @@ class SIREN:
         out = torch.empty((n, self.data_channel), dtype=torch.float32, device=c.device)
         if n == 0:
             return out.view(*lead, self.data_channel)
-        b = _lib.BatchDesc(c.data_ptr(), None, None, None, 0, n)
+        b = _lib.BatchDesc(c.data_ptr(), None, None, None, 0, n, 0, 0, 0)
         _lib.check(_lib.lib().brief_siren_forward(C.byref(self.desc), _lib.ptr(self.packed), None, C.byref(b), _lib.ptr(out),
                                                   _lib.OUT_F32, 0.0, 1.0, 0.0, 1.0, _lib.stream_ptr()))
         return out.view(*lead, self.data_channel)
@@ -247,7 +247,7 @@ class SIREN:
         if out is None:
             out = torch.empty((count, self.data_channel), dtype=dt, device=self.params.device)
         g = self._grid(dims, lo, hi)
-        b = _lib.BatchDesc(None, None, None, None, int(offset), count)
+        b = _lib.BatchDesc(None, None, None, None, int(offset), count, 0, 0, 0)
         _lib.check(_lib.lib().brief_siren_forward(C.byref(self.desc), _lib.ptr(self.packed), C.byref(g), C.byref(b), _lib.ptr(out),
                                                   kind, float(scale[0]), float(scale[1]), float(vrange[0]), float(vrange[1]),
                                                   _lib.stream_ptr()))
@@ -275,7 +275,7 @@ class SIREN:
             g = self._grid(dims, lo, hi)
         b = _lib.BatchDesc(_lib.ptr(coords).value if coords is not None else None, targets.data_ptr(),
                            weights.data_ptr() if weights is not None else None,
-                           idx.data_ptr() if idx is not None else None, int(offset), int(n))
+                           idx.data_ptr() if idx is not None else None, int(offset), int(n), 0, 0, 0)
         _lib.check(_lib.lib().brief_siren_train_step(
             C.byref(self.desc), _lib.ptr(self.packed), C.byref(g) if g is not None else None, C.byref(b),
             _lib.LOSS_KIND[loss], float(thr), float(beta), _lib.ptr(self.grads), _lib.ptr(self._loss), _lib.ptr(yhat),
@@ -283,7 +283,7 @@ class SIREN:
         return self._loss, yhat
 
     def fit_step(self, n, targets, opt_kind, s1, s2, lr, t, idx=None, weights=None, grid=None, offset=0,
-                 loss="datal2", thr=0.0, beta=0.01, betas=(0.9, 0.999), eps=1e-8):
+                 loss="datal2", thr=0.0, beta=0.01, betas=(0.9, 0.999), eps=1e-8, rng=None):
         """train_step + optimizer update + refresh of the packed copy in one C-ABI call (three launches);
         bit-identical to the separate calls.  Returns the device loss tensor."""
         self._require_gpu()
@@ -299,8 +299,9 @@ class SIREN:
             self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev)
         dims, lo, hi = grid
         g = self._grid(dims, lo, hi)
+        pop, seed, step = rng if (rng is not None and idx is None) else (0, 0, 0)      # rng = (pop, seed, step): in-kernel sampling
         b = _lib.BatchDesc(None, targets.data_ptr(), weights.data_ptr() if weights is not None else None,
-                           idx.data_ptr() if idx is not None else None, int(offset), int(n))
+                           idx.data_ptr() if idx is not None else None, int(offset), int(n), int(pop), int(seed), int(step))
         _lib.check(_lib.lib().brief_siren_fit_step(
             C.byref(self.desc), _lib.ptr(self.params), _lib.ptr(self.packed), C.byref(g), C.byref(b),
             _lib.LOSS_KIND[loss], float(thr), float(beta), int(opt_kind), _lib.ptr(s1), _lib.ptr(s2),

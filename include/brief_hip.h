@@ -47,7 +47,9 @@ typedef struct {
 } brief_grid_desc;
 
 /* where the samples of one step come from.
- *   j = idx ? idx[n] : n + offset            (RandompointSampler main.py:154-163 / full-volume cube :112-125)
+ *   j = idx ? idx[n] : (rng_pop > 0 ? philox(rng_seed, rng_step, n) mod-free-scaled to [0, rng_pop) : n + offset)
+ *                                            (RandompointSampler main.py:154-163 / full-volume cube :112-125;
+ *                                             the in-kernel stream equals brief_sample_indices(.., rng_pop, rng_seed, rng_step))
  *   x = coords ? coords[j, :] : grid coordinate of voxel j
  *   y = targets[j, :]      w = weights ? weights[j, :] : 1 */
 typedef struct {
@@ -57,6 +59,8 @@ typedef struct {
     const int64_t *idx;      /* [n] or NULL */
     int64_t offset;
     int64_t n;               /* samples in this call */
+    int64_t rng_pop;         /* > 0 with idx == NULL: draw the voxel indices in-kernel (train step only) */
+    uint64_t rng_seed, rng_step;
 } brief_batch_desc;
 
 typedef enum { BRIEF_LOSS_L2 = 0, BRIEF_LOSS_SMOOTHL1 = 1 } brief_loss_kind;      /* main.py:176-191 */

@@ -311,3 +311,21 @@ def test_fit_step_equals_separate_calls(L, F, name):
         assert torch.equal(la, lb) and torch.equal(ma.grads, mb.grads)
         assert torch.equal(ma.params, mb.params) and torch.equal(sa1, sb1) and torch.equal(sa2, sb2)
         assert torch.equal(ma.packed, mb.packed)
+
+
+def test_in_kernel_sampling_equals_index_kernel():
+    """the Philox stream drawn inside the fused kernel is the one brief_sample_indices writes"""
+    dims = (24, 40, 56)
+    pop = int(np.prod(dims))
+    rng = np.random.default_rng(4)
+    tv = torch.from_numpy(rng.uniform(0, 100, size=(pop, 1)).astype(np.float32)).to(DEV)
+    ma, _, _ = make_net(4, 64, 20.0, seed=5)
+    mb, _, _ = make_net(4, 64, 20.0, seed=5)
+    n = 7001
+    sa1, sa2, sb1, sb2 = (torch.zeros_like(ma.params) for _ in range(4))
+    idx = torch.empty(n, dtype=torch.int64, device=DEV)
+    for t in range(1, 4):
+        _lib.check(_lib.lib().brief_sample_indices(_lib.ptr(idx), n, pop, 99, t, _lib.stream_ptr()))
+        la = ma.fit_step(n, tv, 0, sa1, sa2, 1e-3, t, idx=idx, grid=(dims, -1.0, 1.0)).clone()
+        lb = mb.fit_step(n, tv, 0, sb1, sb2, 1e-3, t, grid=(dims, -1.0, 1.0), rng=(pop, 99, t))
+        assert torch.equal(la, lb) and torch.equal(ma.params, mb.params)
