@@ -83,13 +83,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # "nccl" IS RCCL on ROCm.  BRIEF_DIST_BACKEND=gloo only exists to rehearse the N>1 code path on a
+    # box with fewer GPUs than ranks (ranks then share devices and the reductions go through the host).
+    backend = os.environ.get("BRIEF_DIST_BACKEND", "nccl")
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(local_rank % torch.cuda.device_count())
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
     _lib.lib()   # fails loudly when the HIP extension is missing
 
     # ---- data: this rank's block, generated and normalised on the device (utils/io.py:65-80 op order)
@@ -123,7 +130,7 @@ def main():
     _lib.check(L.brief_profile_fused(C.byref(tot_ms), C.byref(launches)))
     _lib.check(L.brief_profile_enable(0))
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -133,11 +140,10 @@ def main():
         dec = net.decode_grid(BLOCK, out_kind="u16", scale=(0.0, 100.0), vrange=(vmin, vmax))
         sse = torch.zeros(1, dtype=torch.float64, device=dev)
         _lib.check(L.brief_sse_u16(_lib.ptr(vol), _lib.ptr(dec), vol.numel(), _lib.ptr(sse), _lib.stream_ptr()))
-        cnt = torch.tensor([float(vol.numel())], dtype=torch.float64, device=dev)
+        red = torch.tensor([sse.item(), float(vol.numel())], dtype=torch.float64, device=red_dev)
         if dist is not None:
-            dist.all_reduce(sse)
-            dist.all_reduce(cnt)
-        psnr = float(-10.0 * np.log10(sse.item() / cnt.item() / 65535.0 ** 2))
+            dist.all_reduce(red)          # the one collective of the DivideTask path: [SSE, n]
+        psnr = float(-10.0 * np.log10(red[0].item() / red[1].item() / 65535.0 ** 2))
 
     if rank == 0:
         # HBM traffic of the dominant kernel: PMC counters need rocprofv3, so the figure comes from the committed
