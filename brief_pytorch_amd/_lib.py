@@ -39,7 +39,7 @@ OUT_F32, OUT_U8, OUT_U16 = 0, 1, 2
 
 EXPORTS = ["brief_version", "brief_last_error", "brief_param_count", "brief_packed_count",
            "brief_train_workspace_bytes", "brief_siren_repack", "brief_siren_forward", "brief_siren_train_step", "brief_siren_fit_step",
-           "brief_optim_step", "brief_sample_indices", "brief_sse_u16", "brief_profile_enable", "brief_profile_fused", "brief_deblock_edge"]
+           "brief_optim_step", "brief_sample_indices", "brief_sse_u16", "brief_profile_enable", "brief_profile_fused", "brief_deblock_edge", "brief_ssim_u16", "brief_ssim_partial_count"]
 
 
 def needs_build():
@@ -94,6 +94,9 @@ def lib():
     L.brief_sample_indices.argtypes = [vp, C.c_int64, C.c_int64, C.c_uint64, C.c_uint64, vp]
     L.brief_sse_u16.argtypes = [vp, vp, C.c_int64, vp, vp]
     L.brief_deblock_edge.argtypes = [vp, C.c_int64, C.c_int64, C.c_int64] + [C.c_int] * 6 + [C.c_double] * 3 + [C.c_int, vp]
+    L.brief_ssim_partial_count.restype = C.c_int64
+    L.brief_ssim_partial_count.argtypes = [C.c_int64] * 3
+    L.brief_ssim_u16.argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_int64, vp, C.c_double, vp, C.c_int64, vp]
     L.brief_profile_enable.argtypes = [C.c_int]
     L.brief_profile_fused.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     _LIB = L

@@ -78,7 +78,6 @@ struct FusedArgs {
     void *out;           // forward output
     int out_kind;
     float scale_min, den, span, vmin;   // fused invnormalize
-    int dbg;             // ablation flags from BRIEF_DEBUG (timing experiments only)
     int stagger_cus;     // workgroups per residency slot (= CU count)
     int stagger;         // s_sleep(127) units of start delay per slot
 };
@@ -124,7 +123,7 @@ __device__ __forceinline__ void bstore1(float v, __amdgpu_buffer_rsrc_t rs, int 
 // A fragments stream from the packed weight buffer (L2 resident) PD (kt,q)-steps ahead of use.
 template <int NT>
 __device__ __forceinline__ void chain(f32x16 (&acc)[KCfg<NT>::MTW], __amdgpu_buffer_rsrc_t rs, int soff_layer /*bytes*/,
-                                      const float4 *Xs, int wm, int lane, bool dbg_nol2 = false)
+                                      const float4 *Xs, int wm, int lane)
 {
     using K = KCfg<NT>;
     constexpr int NIT = NT * 4;
@@ -134,7 +133,7 @@ __device__ __forceinline__ void chain(f32x16 (&acc)[KCfg<NT>::MTW], __amdgpu_buf
     // opaque to the optimiser: otherwise all 2*NT*4 per-block scalar offsets are hoisted out of the tile
     // loop, spilled to VGPR lanes and fetched back with v_readlane (a VALU op the f32 MFMA has to wait for)
     asm volatile("" : "+s"(soff_w));
-    const int smul = dbg_nol2 ? 0 : 1024;
+    constexpr int smul = 1024;
     float4 areg[NIT][K::MTW];
     float4 breg[NIT];
 #pragma unroll
@@ -258,8 +257,7 @@ __global__ __launch_bounds__(256, TRAIN ? BRIEF_TRAIN_WPE : 3) void k_fused(cons
     const __amdgpu_buffer_rsrc_t rs_pk =
         __builtin_amdgcn_make_buffer_rsrc((void *)pk, 0, (int)(brief_pk_count(d) * 4), 0x00020000);
     const int stash_bytes = (int)((int64_t)K::FP * npad * 4);   // one [FP][npad] panel (host checks < 2^31)
-    const int row_bytes = (a.dbg & 2) ? 0 : (int)(npad * 4);
-    const bool nol2 = (a.dbg & 1) != 0;
+    const int row_bytes = (int)(npad * 4);
 
     // head weights -> LDS once per workgroup (every lane needs all of them in the head dot product)
     {
@@ -370,7 +368,7 @@ __global__ __launch_bounds__(256, TRAIN ? BRIEF_TRAIN_WPE : 3) void k_fused(cons
                         acc[t][4 * q + 2] = bnext[t][q].z; acc[t][4 * q + 3] = bnext[t][q].w;
                     }
                 }
-                chain<NT>(acc, rs_pk, (int)(brief_pk_hidden(d, l) * 4), Xs, wm, lane, nol2);
+                chain<NT>(acc, rs_pk, (int)(brief_pk_hidden(d, l) * 4), Xs, wm, lane);
                 STAMP(1)
                 lds_barrier();   // every wave is done reading the previous image
                 STAMP(2)
@@ -558,7 +556,7 @@ __global__ __launch_bounds__(256, TRAIN ? BRIEF_TRAIN_WPE : 3) void k_fused(cons
             for (int t = 0; t < K::MTW; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-            chain<NT>(acc, rs_pk, (int)((brief_pk_hidden(d, l) + K::FP * K::FP) * 4), Xs, wm, lane, nol2);
+            chain<NT>(acc, rs_pk, (int)((brief_pk_hidden(d, l) + K::FP * K::FP) * 4), Xs, wm, lane);
             STAMP(9)
             // delta_{l-1} = acc * om cos(om z_{l-1})
             const float om = (l - 1) == 0 ? d.w0_first : d.w0_hidden;
@@ -625,8 +623,7 @@ struct WgradArgs {
     int64_t npad;
     int nsplit;
     float *slabs;       // [(L-2)][nsplit][FP*FP + FP]
-    float *stamps;      // diagnostic build only: [blocks][8 waves][8]
-    int dbg;
+    float *stamps;      // diagnostic build (-DBRIEF_STAMPS) only: [blocks][8 waves][8]
 };
 
 template <int NT>
@@ -1062,6 +1059,69 @@ __global__ void k_deblock_edge(uint16_t *img, int64_t H, int64_t W, int z1, int 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// SSIM of the reference (utils/ssim.py:9-150 as called by utils/misc.py:458-475): per z-slice 2-D SSIM with an
+// 11-tap sigma-1.5 separable Gaussian (valid padding, H pass then W pass, f32), K = (0.01, 0.03); the caller
+// averages the per-slice means.  One block = one 16x64 output tile of one slice; partial sums in double.
+#define SSIM_TH 16
+#define SSIM_TW 64
+__global__ __launch_bounds__(256) void k_ssim_u16(const uint16_t *__restrict__ X, const uint16_t *__restrict__ Y, int64_t H, int64_t W,
+                                                    int tiles_h, int tiles_w, const float *__restrict__ win, float C1, float C2,
+                                                    double *__restrict__ partial)
+{
+    __shared__ float sx[SSIM_TH + 10][SSIM_TW + 10], sy[SSIM_TH + 10][SSIM_TW + 10];
+    __shared__ float v[5][SSIM_TH][SSIM_TW + 10];
+    __shared__ float w[11];
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    const int64_t z = blockIdx.x / (tiles_h * tiles_w);
+    const int th = (blockIdx.x / tiles_w) % tiles_h, tw = blockIdx.x % tiles_w;
+    const int64_t oh = H - 10, ow = W - 10;                 // valid output extent
+    const int64_t r0 = (int64_t)th * SSIM_TH, c0 = (int64_t)tw * SSIM_TW;
+    if (tid < 11) w[tid] = win[tid];
+    const uint16_t *xs = X + z * H * W, *ys = Y + z * H * W;
+    for (int e = tid; e < (SSIM_TH + 10) * (SSIM_TW + 10); e += 256) {
+        const int r = e / (SSIM_TW + 10), c = e % (SSIM_TW + 10);
+        const int64_t gr = r0 + r, gc = c0 + c;
+        float a = 0.f, b = 0.f;
+        if (gr < H && gc < W) { a = (float)xs[gr * W + gc]; b = (float)ys[gr * W + gc]; }
+        sx[r][c] = a; sy[r][c] = b;
+    }
+    __syncthreads();
+    for (int e = tid; e < SSIM_TH * (SSIM_TW + 10); e += 256) {      // H pass
+        const int r = e / (SSIM_TW + 10), c = e % (SSIM_TW + 10);
+        float m1 = 0.f, m2 = 0.f, s11 = 0.f, s22 = 0.f, s12 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            const float a = sx[r + k][c], b = sy[r + k][c], wk = w[k];
+            m1 += wk * a; m2 += wk * b; s11 += wk * (a * a); s22 += wk * (b * b); s12 += wk * (a * b);
+        }
+        v[0][r][c] = m1; v[1][r][c] = m2; v[2][r][c] = s11; v[3][r][c] = s22; v[4][r][c] = s12;
+    }
+    __syncthreads();
+    double acc = 0.0;
+    for (int e = tid; e < SSIM_TH * SSIM_TW; e += 256) {             // W pass + SSIM map
+        const int r = e / SSIM_TW, c = e % SSIM_TW;
+        if (r0 + r < oh && c0 + c < ow) {
+            float m1 = 0.f, m2 = 0.f, s11 = 0.f, s22 = 0.f, s12 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; ++k) {
+                const float wk = w[k];
+                m1 += wk * v[0][r][c + k]; m2 += wk * v[1][r][c + k]; s11 += wk * v[2][r][c + k];
+                s22 += wk * v[3][r][c + k]; s12 += wk * v[4][r][c + k];
+            }
+            const float m11 = m1 * m1, m22 = m2 * m2, m12 = m1 * m2;
+            const float sg1 = s11 - m11, sg2 = s22 - m22, sg12 = s12 - m12;
+            const float cs = (2.f * sg12 + C2) / (sg1 + sg2 + C2);
+            acc += (double)(((2.f * m12 + C1) / (m11 + m22 + C1)) * cs);
+        }
+    }
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // =============================================================================================
 // C-ABI
 static thread_local char g_err[512] = "";
@@ -1274,7 +1334,6 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
     fa.loss_kind = loss_kind; fa.thr = thr; fa.beta = beta; fa.inv_count = inv_count;
     fa.Z = ws + wl.z; fa.D = ws + wl.dd; fa.npad = brief_npad(nt, batch->n);
     fa.rec = ws + wl.rec; fa.yhat_out = yhat_out;
-    if (const char *e = getenv("BRIEF_DEBUG")) fa.dbg = atoi(e);
     fa.stagger_cus = kCUs; fa.stagger = g_stagger;
     const bool prof = g_prof_on && g_prof_n < kProfSlots;
     if (prof) HIP_TRY(hipEventRecord(g_prof_ev[2 * g_prof_n], st));
@@ -1286,7 +1345,6 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
         memset(&wa, 0, sizeof(wa));
         wa.d = *d; wa.Z = fa.Z; wa.D = fa.D; wa.npad = fa.npad; wa.nsplit = nsplit; wa.slabs = ws + wl.slabs;
         wa.stamps = ws + wl.rec + (int64_t)kCUs * 4 * 4 * BRIEF_REC_FLOATS - 256 * 8 * 8;   // tail of the record region (diagnostics)
-        wa.dbg = fa.dbg;
         const int blocks = nsplit * (d->layers - 2);
 #define BRIEF_CASE(NTV)                                                                                    \
     case NTV:                                                                                              \
@@ -1393,6 +1451,26 @@ int brief_deblock_edge(uint16_t *img, int64_t D, int64_t H, int64_t W, int z1, i
                        fixed, a1, na, vertical, alpha, beta, thres, mode);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+int brief_ssim_u16(const uint16_t *a, const uint16_t *b, int64_t D, int64_t H, int64_t W, const float *window11, double data_range,
+                   double *partial, int64_t partial_count, void *stream)
+{
+    if (!a || !b || !window11 || !partial || D < 1) return fail(BRIEF_ERR_INVALID, "bad ssim arguments");
+    if (H < 11 || W < 11) return fail(BRIEF_ERR_INVALID, "ssim needs H, W >= 11 (the reference skips the blur on shorter axes)");
+    const int tiles_h = (int)((H - 10 + SSIM_TH - 1) / SSIM_TH), tiles_w = (int)((W - 10 + SSIM_TW - 1) / SSIM_TW);
+    const int64_t blocks = D * tiles_h * tiles_w;
+    if (partial_count < blocks || blocks > 0x7fffffff) return fail(BRIEF_ERR_WORKSPACE, "ssim partial buffer too small");
+    const float C1 = (float)((0.01 * data_range) * (0.01 * data_range)), C2 = (float)((0.03 * data_range) * (0.03 * data_range));
+    hipLaunchKernelGGL(k_ssim_u16, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, b, H, W, tiles_h, tiles_w, window11, C1, C2, partial);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int64_t brief_ssim_partial_count(int64_t D, int64_t H, int64_t W)
+{
+    if (H < 11 || W < 11 || D < 1) return -1;
+    return D * ((H - 10 + SSIM_TH - 1) / SSIM_TH) * ((W - 10 + SSIM_TW - 1) / SSIM_TW);
 }
 
 int brief_sample_indices(int64_t *idx, int64_t n, int64_t pop, uint64_t seed, uint64_t step, void *stream)

@@ -21,7 +21,7 @@ import torch
 from . import _lib, config
 from .fit import Fitter
 from .io import get_folder_size, get_type_max, invnormalize_data, minmaxany_range, normalize_data, save_yaml, load_yaml
-from .metrics import cal_ssim, eval_performance, psnr_from_sse
+from .metrics import cal_ssim, eval_performance, gpu_eval_u16, gpu_ssim_u16, psnr_from_sse
 from .misc import (alloc_param, cal_divide_num, divide_data, merge_divided_data, mip_ops, parse_checkpoints,
                    parse_chunk_name, parse_weight, preprocess)
 from .modelsave import CopyDir, load_model, save_model
@@ -218,7 +218,12 @@ class NFGR:
                         for tag, vol in ((name, data), (name + "_decompressed", dec)):
                             for ax, img in zip("dhw", mip_ops(vol)):
                                 save_img(opj(mdir, "%s_mip_%s%s" % (tag, ax, ext)), img)
-                    perf = eval_performance(steps, data, dec, Log, opt.Decompress.mse, opt.Decompress.psnr, opt.Decompress.ssim)
+                    if data.dtype == np.uint16 and data.ndim == 4 and data.shape[-1] == 1 and min(data.shape[1:3]) >= 11:
+                        perf = {"steps": steps, **gpu_eval_u16(data, dec, opt.Decompress.mse, opt.Decompress.psnr, opt.Decompress.ssim)}
+                        if Log is not None:
+                            Log.log_metrics({k: v for k, v in perf.items() if k != "steps"}, steps)
+                    else:
+                        perf = eval_performance(steps, data, dec, Log, opt.Decompress.mse, opt.Decompress.psnr, opt.Decompress.ssim)
                     perf["loss"] = float(loss.item())
                     _append_csv(opj(logdir, "performance.csv"), perf)
                     results[steps] = perf
@@ -333,7 +338,11 @@ class NFGR:
                     if self.opt.Decompress.mse:
                         perf["mse"] = sse_all / float(data.size)
                     if self.opt.Decompress.ssim:
-                        perf["ssim"] = cal_ssim(data.astype(np.float32), merged.astype(np.float32), drange)
+                        if data.dtype == np.uint16 and data.shape[-1] == 1 and min(data.shape[1:3]) >= 11:
+                            ss, ns = gpu_ssim_u16(torch.from_numpy(np.ascontiguousarray(data)).cuda(), torch.from_numpy(np.ascontiguousarray(merged)).cuda())
+                            perf["ssim"] = ss / ns
+                        else:
+                            perf["ssim"] = cal_ssim(data.astype(np.float32), merged.astype(np.float32), drange)
                     orig_bytes = os.path.getsize(data_path) if os.path.exists(data_path) else data.nbytes
                     cdir = opj(sdir, "compressed")
                     theory = get_folder_size(opj(cdir, "sideinfos")) + sum(c["theory_module_size"] for c in chunks)

@@ -80,3 +80,43 @@ def eval_performance(steps, data1, data2, Log, mse, psnr, ssim):
         if Log is not None:
             Log.log_metrics({"ssim": perf["ssim"]}, steps)
     return perf
+
+
+def gpu_ssim_u16(a, b, data_range=65535):
+    """cal_ssim for single-channel uint16 volumes resident on the GPU: tensors (d,h,w) or (d,h,w,1).
+    Returns (sum of per-slice means, slices) so that ranks can all-reduce both; SSIM = sum / slices."""
+    import ctypes as C
+    import torch
+    from . import _lib
+    d, h, w = a.shape[:3]
+    L = _lib.lib()
+    n = L.brief_ssim_partial_count(d, h, w)
+    if n < 0:
+        raise _lib.BriefError("gpu_ssim_u16 needs h, w >= 11")
+    part = torch.empty(n, dtype=torch.float64, device=a.device)
+    win = torch.from_numpy(_gauss_win()).to(a.device)
+    _lib.check(L.brief_ssim_u16(_lib.ptr(a), _lib.ptr(b), d, h, w, _lib.ptr(win), float(data_range), _lib.ptr(part), n, _lib.stream_ptr()))
+    per_slice = part.view(d, -1).sum(1) / float((h - 10) * (w - 10))
+    return float(per_slice.sum().item()), d
+
+
+def gpu_eval_u16(orig, dec, mse=True, psnr=True, ssim=True):
+    """eval_performance (utils/misc.py:477-499) for single-channel uint16 volumes on the GPU: SSE by
+    brief_sse_u16, SSIM by brief_ssim_u16.  orig/dec: numpy (d,h,w,1)."""
+    import torch
+    from . import _lib
+    a = torch.from_numpy(np.ascontiguousarray(orig)).cuda()
+    b = torch.from_numpy(np.ascontiguousarray(dec)).cuda()
+    out = {}
+    if mse or psnr:
+        sse = torch.zeros(1, dtype=torch.float64, device=a.device)
+        _lib.check(_lib.lib().brief_sse_u16(_lib.ptr(a), _lib.ptr(b), a.numel(), _lib.ptr(sse), _lib.stream_ptr()))
+        v = sse.item()
+        if mse:
+            out["mse"] = v / a.numel()
+        if psnr:
+            out["psnr"] = psnr_from_sse(v, a.numel(), 65535)
+    if ssim:
+        s, n = gpu_ssim_u16(a, b)
+        out["ssim"] = s / n
+    return out

@@ -118,6 +118,14 @@ int brief_sample_indices(int64_t *idx, int64_t n, int64_t pop, uint64_t seed, ui
 /* sum of squared differences of two integer volumes (for PSNR, utils/misc.py:451-456); sse_out: one double */
 int brief_sse_u16(const uint16_t *a, const uint16_t *b, int64_t n, double *sse_out, void *stream);
 
+/* cal_ssim of utils/misc.py:458-475 for single-channel uint16 volumes [D,H,W]: per z-slice 2-D SSIM (utils/ssim.py:
+ * 11-tap Gaussian `window11`, valid padding, K=(0.01,0.03)).  Writes one double per 16x64 output tile, slice-major
+ * (brief_ssim_partial_count of them; tiles of slice z are contiguous); slice mean = sum of its tiles / ((H-10)(W-10)),
+ * SSIM = mean over slices.  Across ranks: all-reduce [sum of slice means, slices]. */
+int64_t brief_ssim_partial_count(int64_t D, int64_t H, int64_t W);
+int brief_ssim_u16(const uint16_t *a, const uint16_t *b, int64_t D, int64_t H, int64_t W, const float *window11, double data_range,
+                   double *partial, int64_t partial_count, void *stream);
+
 /* Block-boundary filter of DivideTask outputs (reference deblock.py:52-78 / deblock.cpp:277-319): filters the
  * boundary line  x == fixed, y in [a1,a2]  (vertical != 0)  or  y == fixed, x in [a1,a2]  (vertical == 0)  of
  * every slice z1..z2 of a uint16 volume [D,H,W] in place.  mode 1 = deblock.py arithmetic, 0 = deblock.cpp

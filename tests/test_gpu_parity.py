@@ -329,3 +329,21 @@ def test_in_kernel_sampling_equals_index_kernel():
         la = ma.fit_step(n, tv, 0, sa1, sa2, 1e-3, t, idx=idx, grid=(dims, -1.0, 1.0)).clone()
         lb = mb.fit_step(n, tv, 0, sb1, sb2, 1e-3, t, grid=(dims, -1.0, 1.0), rng=(pop, 99, t))
         assert torch.equal(la, lb) and torch.equal(ma.params, mb.params)
+
+
+def test_gpu_ssim_vs_reference_golden(golden):
+    from brief_pytorch_amd.metrics import gpu_ssim_u16
+    g = golden("decode")
+    a, b = torch.from_numpy(g["vol"].copy()).to(DEV), torch.from_numpy(g["dec_u16"].copy()).to(DEV)
+    s, n = gpu_ssim_u16(a, b)
+    assert n == g["vol"].shape[0] and abs(s / n - g["ssim"][0]) < 2e-5
+    pa, pb = torch.from_numpy(g["pair_a"].copy()).to(DEV), torch.from_numpy(g["pair_b"].copy()).to(DEV)
+    s, n = gpu_ssim_u16(pa, pb)
+    assert abs(s / n - g["pair_ssim"][0]) < 2e-5
+    # a larger, ragged volume against the oracle's float64 restatement
+    from brief_pytorch_amd.synthetic import make_volume
+    v = make_volume((7, 83, 141), seed=31)
+    rng = np.random.default_rng(1)
+    u = np.clip(v.astype(np.int64) + rng.integers(-400, 400, size=v.shape), 0, 65535).astype(np.uint16)
+    s, n = gpu_ssim_u16(torch.from_numpy(v).to(DEV), torch.from_numpy(u).to(DEV))
+    assert abs(s / n - O.ssim(v.astype(np.float32), u.astype(np.float32), 65535)) < 5e-5

@@ -1,6 +1,6 @@
 """scratch: read the cycle stamps of the diagnostic k_fused build"""
 import shutil, sys
-shutil.copy('brief_pytorch_amd/libbrief_hip_stamps.so', 'brief_pytorch_amd/libbrief_hip.so')
+import os; os.environ["BRIEF_LIB"] = os.path.abspath("brief_pytorch_amd/libbrief_hip_stamps.so")
 import torch, numpy as np
 sys.path.insert(0, '.')
 from brief_pytorch_amd import _lib
