@@ -95,3 +95,33 @@ def make_volume_torch(shape, seed=42, device="cuda", n_waves=8, n_blobs=32, nois
         v = base + span * f + noise_sigma * torch.randn(f.shape, device=device, generator=gen)
         out[z0:z1, :, :, 0] = v.round().clamp_(0, 65535).to(torch.int32).to(torch.uint16)
     return out
+
+
+def ensure_dataset(path):
+    """`dataset/synthetic_<n>.tif` (or `synthetic_<d>x<h>x<w>.tif`) is generated on first use; any other
+    missing path is an error.  The reference's sample volumes are not redistributed here."""
+    import os
+    import re
+    if os.path.exists(path):
+        return path
+    m = re.fullmatch(r"synthetic_(\d+)(?:x(\d+)x(\d+))?\.tiff?", os.path.basename(path))
+    if not m:
+        raise FileNotFoundError(path)
+    d = int(m.group(1))
+    shape = (d, int(m.group(2)), int(m.group(3))) if m.group(2) else (d, d, d)
+    from .tool import save_img
+    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    save_img(path, make_volume(shape, seed=42))
+    return path
+
+
+if __name__ == "__main__":
+    import argparse
+    ap = argparse.ArgumentParser(description="write a synthetic uint16 test volume")
+    ap.add_argument("--shape", type=int, nargs=3, default=[64, 64, 64])
+    ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--out", type=str, required=True)
+    a = ap.parse_args()
+    from .tool import save_img
+    save_img(a.out, make_volume(a.shape, seed=a.seed))
+    print("wrote", a.out)

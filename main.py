@@ -63,6 +63,11 @@ def main(argv=None):
     reproduc(opt.Reproduc)
     cf = opt.CompressFramework
     cf["_seed"] = opt.Reproduc.seed
+    from brief_pytorch_amd.synthetic import ensure_dataset
+    if int(os.environ.get("RANK", "0")) == 0:
+        ensure_dataset(opt.Dataset.data_path)      # dataset/synthetic_<n>.tif is generated on first use
+    if world > 1:
+        torch.distributed.barrier()
     fw = NFGR(cf, Log=Log, args=args)
     if cf.Compress.divide.divide_type == "none":
         res = fw.compress(opt.Dataset.data_path)

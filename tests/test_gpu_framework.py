@@ -90,3 +90,24 @@ def test_dividetask_single_rank(tmp_path):
     merged = read_img(os.path.join(Log.logdir, "steps200", "decompressed", "blk_decompressed.tif"))
     d = merged.astype(np.float64) - vol.astype(np.float64)
     assert abs(-10 * np.log10((d * d).mean() / 65535.0 ** 2) - res[200]["psnr"]) < 1e-6
+
+
+def test_cli_singletask_end_to_end(tmp_path, monkeypatch):
+    """python main.py -p <yaml>: the drop-in CLI on a generated 24x32x40 volume (randomcube -> full batch)"""
+    import subprocess
+    import sys
+    opt = config.load(os.path.join(ROOT, "opt", "SingleTask", "default.yaml"))
+    opt.Dataset.data_path = str(tmp_path / "dataset" / "synthetic_24x32x40.tif")
+    opt.CompressFramework.Compress.max_steps = 150
+    opt.CompressFramework.Compress.checkpoints = "none"
+    opt.Log.outputs_dir = str(tmp_path / "outputs")
+    opt.Log.time = False
+    y = str(tmp_path / "cli.yaml")
+    config.save(opt, y)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "main.py"), "-p", y, "-g", "0"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "steps 150" in r.stdout and "psnr" in r.stdout
+    run = os.path.join(str(tmp_path / "outputs"), "single")
+    assert os.path.exists(os.path.join(run, "steps150", "compressed", "module", "weight-0-21-3")) or \
+        any(f.startswith("weight-0-") for f in os.listdir(os.path.join(run, "steps150", "compressed", "module")))
+    assert os.path.exists(os.path.join(run, "performance.csv"))
