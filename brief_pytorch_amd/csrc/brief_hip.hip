@@ -626,11 +626,25 @@ struct WgradArgs {
     float *stamps;      // diagnostic build (-DBRIEF_STAMPS) only: [blocks][8 waves][8]
 };
 
+// dynamic LDS of k_wgrad<NT> in floats: two double-buffered panel pairs, or the k-slice fold area if larger
+constexpr int wgrad_lds_floats(int NT)
+{
+    const int WMk = NT >= 2 ? 2 : 1, WNk = NT >= 5 ? 4 : (NT >= 2 ? 2 : 1), WK = NT >= 5 ? 1 : (NT >= 2 ? 2 : 4);
+    const int NWv = WMk * WNk, TM = (NT + WMk - 1) / WMk, TN = (NT + WNk - 1) / WNk;
+    const int fold = (WK - 1) * NWv * TM * TN * 1024 + (WK - 1) * NWv * TM * 64, panels = 4 * 32 * NT * 36;
+    return fold > panels ? fold : panels;
+}
+
 template <int NT>
 __global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
 {
     constexpr int FP = 32 * NT;
-    constexpr int WMk = 2, WNk = 4;
+    // 8 waves = WMk x WNk output-tile grid x WK-way split of each chunk's four k-groups.  Wide nets spend
+    // all 8 waves on output tiles; narrow ones (NT <= 4) would leave most waves without a tile, so they
+    // split K instead and fold the partial accumulators through LDS at the end (fixed order).
+    constexpr int WMk = NT >= 2 ? 2 : 1, WNk = NT >= 5 ? 4 : (NT >= 2 ? 2 : 1);
+    constexpr int WK = NT >= 5 ? 1 : (NT >= 2 ? 2 : 4);
+    constexpr int NWv = WMk * WNk;                 // waves per k-slice
     constexpr int TM = (NT + WMk - 1) / WMk, TN = (NT + WNk - 1) / WNk;
     constexpr bool MEX = NT % WMk == 0, NEX = NT % WNk == 0;   // every wave tile exists
     constexpr int LDSW = 36;                       // row stride (floats): conflict-free ds_read_b128
@@ -643,7 +657,9 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5, ln = lane & 31;
-    const int wmk = wave / WNk, wnk = wave % WNk;
+    const int wk = wave / NWv, wrem = wave % NWv;
+    const int wmk = wrem / WNk, wnk = wrem % WNk;
+    const bool kactive = wk < WK;                  // NT == 1 uses 4 of the 8 waves for MFMA work
     const int l = 1 + blockIdx.x / a.nsplit;       // hidden layer 1..L-2
     const int split = blockIdx.x % a.nsplit;
     const int64_t nchunks = a.npad / 32;
@@ -720,29 +736,31 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
         STAMP(0)
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
-            float4 af[TM], bf[TN];
+            if (WK == 1 || (kactive && (gq % WK) == wk)) {
+                float4 af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int mt = wmk * TM + i;
-                af[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (MEX || mt < NT) af[i] = *reinterpret_cast<const float4 *>(As + (32 * mt + ln) * LDSW + 8 * gq + 4 * hi);
-                if (wnk == 0) dbacc[i] += (af[i].x + af[i].y) + (af[i].z + af[i].w);
-            }
-#pragma unroll
-            for (int jn = 0; jn < TN; ++jn) {
-                const int nt = wnk * TN + jn;
-                bf[jn] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (NEX || nt < NT) bf[jn] = *reinterpret_cast<const float4 *>(Bs + (32 * nt + ln) * LDSW + 8 * gq + 4 * hi);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
+                for (int i = 0; i < TM; ++i) {
+                    const int mt = wmk * TM + i;
+                    af[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (MEX || mt < NT) af[i] = *reinterpret_cast<const float4 *>(As + (32 * mt + ln) * LDSW + 8 * gq + 4 * hi);
+                    if (wnk == 0) dbacc[i] += (af[i].x + af[i].y) + (af[i].z + af[i].w);
+                }
 #pragma unroll
                 for (int jn = 0; jn < TN; ++jn) {
-                    if ((MEX || wmk * TM + i < NT) && (NEX || wnk * TN + jn < NT)) {
-                        acc[i][jn] = MFMA(af[i].x, bf[jn].x, acc[i][jn]);
-                        acc[i][jn] = MFMA(af[i].y, bf[jn].y, acc[i][jn]);
-                        acc[i][jn] = MFMA(af[i].z, bf[jn].z, acc[i][jn]);
-                        acc[i][jn] = MFMA(af[i].w, bf[jn].w, acc[i][jn]);
+                    const int nt = wnk * TN + jn;
+                    bf[jn] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (NEX || nt < NT) bf[jn] = *reinterpret_cast<const float4 *>(Bs + (32 * nt + ln) * LDSW + 8 * gq + 4 * hi);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                    for (int jn = 0; jn < TN; ++jn) {
+                        if ((MEX || wmk * TM + i < NT) && (NEX || wnk * TN + jn < NT)) {
+                            acc[i][jn] = MFMA(af[i].x, bf[jn].x, acc[i][jn]);
+                            acc[i][jn] = MFMA(af[i].y, bf[jn].y, acc[i][jn]);
+                            acc[i][jn] = MFMA(af[i].z, bf[jn].z, acc[i][jn]);
+                            acc[i][jn] = MFMA(af[i].w, bf[jn].w, acc[i][jn]);
+                        }
                     }
                 }
             }
@@ -769,6 +787,38 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
 #undef WG_ISSUE
 #undef WG_STAGE_A
 #undef WG_STAGE_B
+    if (WK > 1) {
+        // fold the k-slices: slices 1..WK-1 park their accumulators in LDS (the panels are dead now: the
+        // loop ended on a barrier), slice 0 adds them in slice order
+        float *red = smem;
+        float *redb = smem + (WK - 1) * NWv * TM * TN * 1024;
+        if (kactive && wk > 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        red[((((wk - 1) * NWv + wrem) * TM + i) * TN + jn) * 1024 + r * 64 + lane] = acc[i][jn][r];
+                redb[(((wk - 1) * NWv + wrem) * TM + i) * 64 + lane] = dbacc[i];
+            }
+        }
+        lds_barrier();
+        if (wk == 0) {
+            for (int w = 1; w < WK; ++w) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                    for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            acc[i][jn][r] += red[((((w - 1) * NWv + wrem) * TM + i) * TN + jn) * 1024 + r * 64 + lane];
+                    dbacc[i] += redb[(((w - 1) * NWv + wrem) * TM + i) * 64 + lane];
+                }
+            }
+        }
+    }
+    if (wk != 0) return;
     float *slab = a.slabs + ((int64_t)(l - 1) * a.nsplit + split) * ((int64_t)FP * FP + FP);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -1348,7 +1398,7 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
         const int blocks = nsplit * (d->layers - 2);
 #define BRIEF_CASE(NTV)                                                                                    \
     case NTV:                                                                                              \
-        hipLaunchKernelGGL((k_wgrad<NTV>), dim3(blocks), dim3(512), sizeof(float) * 4 * 32 * NTV * 36, st, wa); \
+        hipLaunchKernelGGL((k_wgrad<NTV>), dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(NTV), st, wa); \
         break;
         switch (nt) {
             BRIEF_CASE(1) BRIEF_CASE(2) BRIEF_CASE(3) BRIEF_CASE(4)
