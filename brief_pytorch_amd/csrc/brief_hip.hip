@@ -46,7 +46,9 @@ struct KCfg {
     static constexpr bool EXACT = (NT % WM) == 0;
     static constexpr int FP = 32 * NT;
     static constexpr int XS_FLOATS = WS * NT * 1024;  // activation image(s)
-    static constexpr int T_FLOATS = 4 * 64 * 33;      // per-wave transposed scratch
+    static constexpr int TROWS = 32 * MTW;            // local features one wave owns
+    static constexpr int RS = (TROWS + 63) / 64;      // local-feature slots per lane in the skinny-gradient pass
+    static constexpr int T_FLOATS = 4 * TROWS * 33;   // per-wave transposed scratch
     static constexpr int G_FLOATS = 4 * 256;          // per-wave g[4][32] + xs[32][4]
 };
 
@@ -208,7 +210,7 @@ __device__ __forceinline__ int64_t philox_index(int64_t i, uint64_t pop, uint64_
 
 // LDS map of k_fused (floats):  R = max(image, transpose scratch) | G (per-wave g / coords) | HW (head weights)
 //   image  X : WS x NT x 1024            activation register image(s)
-//   scratch T: 4 waves x 64 x 33          per-wave [feature][sample] transpose (aliases X: used only while
+//   scratch T: 4 waves x 32*MTW x 33      per-wave [feature][sample] transpose (aliases X: used only while
 //                                         no wave reads the image, see the barriers below)
 template <int NT>
 struct FusedLds {
@@ -228,7 +230,7 @@ struct FusedLds {
 #define STAMP(slot)
 #endif
 template <int NT, bool TRAIN>
-__global__ __launch_bounds__(256, TRAIN ? BRIEF_TRAIN_WPE : 3) void k_fused(const FusedArgs a)
+__global__ __launch_bounds__(256, TRAIN ? (NT > 8 ? 1 : BRIEF_TRAIN_WPE) : (NT > 8 ? 2 : 3)) void k_fused(const FusedArgs a)
 {
 #ifdef BRIEF_STAMPS
     float st_acc[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(256, TRAIN ? BRIEF_TRAIN_WPE : 3) void k_fused(cons
     const int64_t npad = a.npad;
     const float *pk = a.pk;
     float4 *Xs = X + ws * (NT * 256);
-    float *Tw = T + wave * (64 * 33);
+    float *Tw = T + wave * (K::TROWS * 33);
     float *Gw = G + wave * 256;
     const float4 *W0p = reinterpret_cast<const float4 *>(pk + brief_pk_w0(d));
     const __amdgpu_buffer_rsrc_t rs_pk =
@@ -273,8 +275,11 @@ __global__ __launch_bounds__(256, TRAIN ? BRIEF_TRAIN_WPE : 3) void k_fused(cons
     lds_barrier();
 
     // persistent skinny-gradient accumulators (lane <-> local feature)
-    float acc0[4] = {0.f, 0.f, 0.f, 0.f};
-    float accWh[4] = {0.f, 0.f, 0.f, 0.f};
+    float acc0[K::RS][4], accWh[K::RS][4];
+#pragma unroll
+    for (int rs = 0; rs < K::RS; ++rs)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { acc0[rs][c] = 0.f; accWh[rs][c] = 0.f; }
     float accbh[4] = {0.f, 0.f, 0.f, 0.f};
     float lsum = 0.f;
 
@@ -478,9 +483,11 @@ __global__ __launch_bounds__(256, TRAIN ? BRIEF_TRAIN_WPE : 3) void k_fused(cons
         if (hi == 0) *reinterpret_cast<float4 *>(Gw + ln * 4) = make_float4(g[0], g[1], g[2], g[3]);
         else *reinterpret_cast<float4 *>(Gw + 128 + ln * 4) = make_float4(x0, x1, x2, 1.0f);
         lds_barrier();
-        {
+#pragma unroll
+        for (int rs = 0; rs < K::RS; ++rs) {
             float4 sW = make_float4(0.f, 0.f, 0.f, 0.f), sb = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float *trow = Tw + lane * 33;
+            const int row = lane + 64 * rs;
+            const float *trow = Tw + (row < K::TROWS ? row : 0) * 33;
 #pragma unroll 4
             for (int s = 0; s < 32; ++s) {
                 const float hv = trow[s];
@@ -489,8 +496,8 @@ __global__ __launch_bounds__(256, TRAIN ? BRIEF_TRAIN_WPE : 3) void k_fused(cons
                 sW.z = __fmaf_rn(hv, gv.z, sW.z); sW.w = __fmaf_rn(hv, gv.w, sW.w);
                 sb.x += gv.x; sb.y += gv.y; sb.z += gv.z; sb.w += gv.w;
             }
-            if (lane < 32 * K::MTW) { accWh[0] += sW.x; accWh[1] += sW.y; accWh[2] += sW.z; accWh[3] += sW.w; }
-            accbh[0] += sb.x; accbh[1] += sb.y; accbh[2] += sb.z; accbh[3] += sb.w;
+            if (row < K::TROWS) { accWh[rs][0] += sW.x; accWh[rs][1] += sW.y; accWh[rs][2] += sW.z; accWh[rs][3] += sW.w; }
+            if (rs == 0) { accbh[0] += sb.x; accbh[1] += sb.y; accbh[2] += sb.z; accbh[3] += sb.w; }
         }
         // ---- delta of the last sine layer: c * (Wh^T g)
         f32x16 dl[K::MTW];
@@ -579,9 +586,11 @@ __global__ __launch_bounds__(256, TRAIN ? BRIEF_TRAIN_WPE : 3) void k_fused(cons
             for (int r = 0; r < 16; ++r) Tw[(32 * t + ROWMAP(r, hi)) * 33 + ln] = dl[t][r];
         }
         lds_barrier();
-        {
+#pragma unroll
+        for (int rs = 0; rs < K::RS; ++rs) {
             float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float *trow = Tw + lane * 33;
+            const int row = lane + 64 * rs;
+            const float *trow = Tw + (row < K::TROWS ? row : 0) * 33;
 #pragma unroll 4
             for (int s = 0; s < 32; ++s) {
                 const float dv = trow[s];
@@ -589,7 +598,7 @@ __global__ __launch_bounds__(256, TRAIN ? BRIEF_TRAIN_WPE : 3) void k_fused(cons
                 s0.x = __fmaf_rn(dv, xv.x, s0.x); s0.y = __fmaf_rn(dv, xv.y, s0.y);
                 s0.z = __fmaf_rn(dv, xv.z, s0.z); s0.w = __fmaf_rn(dv, xv.w, s0.w);
             }
-            if (lane < 32 * K::MTW) { acc0[0] += s0.x; acc0[1] += s0.y; acc0[2] += s0.z; acc0[3] += s0.w; }
+            if (row < K::TROWS) { acc0[rs][0] += s0.x; acc0[rs][1] += s0.y; acc0[rs][2] += s0.z; acc0[rs][3] += s0.w; }
         }
         lds_barrier();
         STAMP(6)
@@ -598,17 +607,23 @@ __global__ __launch_bounds__(256, TRAIN ? BRIEF_TRAIN_WPE : 3) void k_fused(cons
     if (TRAIN) {
         float *rec = a.rec + ((int64_t)blockIdx.x * 4 + wave) * BRIEF_REC_FLOATS;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            rec[lane * 4 + c] = acc0[c];          // dW0[f_local][x0,x1,x2,bias]
-            rec[256 + c * 64 + lane] = accWh[c];  // dWh[c][f_local]
+        for (int rs = 0; rs < K::RS; ++rs) {
+            const int row = lane + 64 * rs;
+            if (row < 128) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    rec[row * 4 + c] = acc0[rs][c];                        // dW0[f_local][x0,x1,x2,bias]
+                    rec[BRIEF_REC_DWH + c * 128 + row] = accWh[rs][c];     // dWh[c][f_local]
+                }
+            }
         }
         for (int off = 32; off >= 1; off >>= 1) lsum += __shfl_xor(lsum, off);
         if (lane == 0) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) rec[512 + c] = accbh[c];
-            rec[516] = lsum;
+            for (int c = 0; c < 4; ++c) rec[BRIEF_REC_DBH + c] = accbh[c];
+            rec[BRIEF_REC_LOSS] = lsum;
 #ifdef BRIEF_STAMPS
-            for (int i = 0; i < 10; ++i) rec[518 + i] = st_acc[i];
+            for (int i = 0; i < 10; ++i) rec[BRIEF_REC_STAMPS + i] = st_acc[i];
 #endif
         }
     }
@@ -626,12 +641,17 @@ struct WgradArgs {
     float *stamps;      // diagnostic build (-DBRIEF_STAMPS) only: [blocks][8 waves][8]
 };
 
-// dynamic LDS of k_wgrad<NT> in floats: two double-buffered panel pairs, or the k-slice fold area if larger
+// k_wgrad<NT> geometry.  Widths above 8 tiles are cut into NQ x NQ output quadrants of QT x QT tiles, one
+// workgroup each (a 512x512 fp32 dW does not fit eight waves' registers); QT plays NT's role inside.
+constexpr int wgrad_nq(int NT) { return NT > 8 ? 2 : 1; }
+constexpr int wgrad_qt(int NT) { return NT / wgrad_nq(NT); }
+// dynamic LDS in floats: two double-buffered panel pairs, or the k-slice fold area if larger
 constexpr int wgrad_lds_floats(int NT)
 {
-    const int WMk = NT >= 2 ? 2 : 1, WNk = NT >= 5 ? 4 : (NT >= 2 ? 2 : 1), WK = NT >= 5 ? 1 : (NT >= 2 ? 2 : 4);
-    const int NWv = WMk * WNk, TM = (NT + WMk - 1) / WMk, TN = (NT + WNk - 1) / WNk;
-    const int fold = (WK - 1) * NWv * TM * TN * 1024 + (WK - 1) * NWv * TM * 64, panels = 4 * 32 * NT * 36;
+    const int QT = wgrad_qt(NT);
+    const int WMk = QT >= 2 ? 2 : 1, WNk = QT >= 5 ? 4 : (QT >= 2 ? 2 : 1), WK = QT >= 5 ? 1 : (QT >= 2 ? 2 : 4);
+    const int NWv = WMk * WNk, TM = (QT + WMk - 1) / WMk, TN = (QT + WNk - 1) / WNk;
+    const int fold = (WK - 1) * NWv * TM * TN * 1024 + (WK - 1) * NWv * TM * 64, panels = 4 * 32 * QT * 36;
     return fold > panels ? fold : panels;
 }
 
@@ -639,18 +659,19 @@ template <int NT>
 __global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
 {
     constexpr int FP = 32 * NT;
+    constexpr int NQ = wgrad_nq(NT), QT = wgrad_qt(NT), QP = 32 * QT;   // quadrants per side, tiles / rows per quadrant side
     // 8 waves = WMk x WNk output-tile grid x WK-way split of each chunk's four k-groups.  Wide nets spend
-    // all 8 waves on output tiles; narrow ones (NT <= 4) would leave most waves without a tile, so they
+    // all 8 waves on output tiles; narrow ones (QT <= 4) would leave most waves without a tile, so they
     // split K instead and fold the partial accumulators through LDS at the end (fixed order).
-    constexpr int WMk = NT >= 2 ? 2 : 1, WNk = NT >= 5 ? 4 : (NT >= 2 ? 2 : 1);
-    constexpr int WK = NT >= 5 ? 1 : (NT >= 2 ? 2 : 4);
+    constexpr int WMk = QT >= 2 ? 2 : 1, WNk = QT >= 5 ? 4 : (QT >= 2 ? 2 : 1);
+    constexpr int WK = QT >= 5 ? 1 : (QT >= 2 ? 2 : 4);
     constexpr int NWv = WMk * WNk;                 // waves per k-slice
-    constexpr int TM = (NT + WMk - 1) / WMk, TN = (NT + WNk - 1) / WNk;
-    constexpr bool MEX = NT % WMk == 0, NEX = NT % WNk == 0;   // every wave tile exists
+    constexpr int TM = (QT + WMk - 1) / WMk, TN = (QT + WNk - 1) / WNk;
+    constexpr bool MEX = QT % WMk == 0, NEX = QT % WNk == 0;   // every wave tile exists
     constexpr int LDSW = 36;                       // row stride (floats): conflict-free ds_read_b128
-    constexpr int NLD = (FP * 8 + 511) / 512;      // float4 loads per thread per operand per chunk
-    constexpr int PANEL = FP * LDSW;
-    constexpr bool FULL = (FP * 8) % 512 == 0;     // every thread has a slot in every staging pass
+    constexpr int NLD = (QP * 8 + 511) / 512;      // float4 loads per thread per operand per chunk
+    constexpr int PANEL = QP * LDSW;
+    constexpr bool FULL = (QP * 8) % 512 == 0;     // every thread has a slot in every staging pass
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [2 buffers][A panel | B panel]
 
     const int tid = threadIdx.x;
@@ -659,14 +680,16 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
     const int hi = lane >> 5, ln = lane & 31;
     const int wk = wave / NWv, wrem = wave % NWv;
     const int wmk = wrem / WNk, wnk = wrem % WNk;
-    const bool kactive = wk < WK;                  // NT == 1 uses 4 of the 8 waves for MFMA work
-    const int l = 1 + blockIdx.x / a.nsplit;       // hidden layer 1..L-2
-    const int split = blockIdx.x % a.nsplit;
+    const bool kactive = wk < WK;                  // QT == 1 uses 4 of the 8 waves for MFMA work
+    const int quad = blockIdx.x % (NQ * NQ), bsl = blockIdx.x / (NQ * NQ);
+    const int qm = quad / NQ, qn = quad % NQ;
+    const int l = 1 + bsl / a.nsplit;              // hidden layer 1..L-2
+    const int split = bsl % a.nsplit;
     const int64_t nchunks = a.npad / 32;
     const int64_t c0 = nchunks * split / a.nsplit, c1 = nchunks * (split + 1) / a.nsplit;   // c1 > c0 (host: nsplit <= nchunks)
     const float om = (l - 1) == 0 ? a.d.w0_first : a.d.w0_hidden;
-    const float *Dl = a.D + (int64_t)(l - 1) * FP * a.npad;
-    const float *Zl = a.Z + (int64_t)(l - 1) * FP * a.npad;
+    const float *Dl = a.D + ((int64_t)(l - 1) * FP + qm * QP) * a.npad;     // this quadrant's delta rows
+    const float *Zl = a.Z + ((int64_t)(l - 1) * FP + qn * QP) * a.npad;     // ... and z rows
 
     f32x16 acc[TM][TN];
     float dbacc[TM];
@@ -683,7 +706,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
     // clamped to the last chunk instead of being skipped (the redundant copies are never read).
     // panel rows are npad*4 bytes apart: one fixed per-thread byte offset per staging pass, the chunk
     // offset is a scalar (no per-load 64-bit address arithmetic on the VALU, which the f32 MFMA shares)
-    const int panel_bytes = (int)((int64_t)FP * a.npad * 4);
+    const int panel_bytes = (int)((int64_t)QP * a.npad * 4);
     const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void *)Dl, 0, panel_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc((void *)Zl, 0, panel_bytes, 0x00020000);
     int voffs[NLD];
@@ -697,7 +720,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
         const int e = tid + 512 * i;                                                              \
         ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);                                                  \
         rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);                                                  \
-        if (FULL || e < FP * 8) {                                                                 \
+        if (FULL || e < QP * 8) {                                                                 \
             ra[i] = bload4(rsD, voffs[i], (int)((cc) * 128));                                     \
             rb[i] = bload4(rsZ, voffs[i], (int)((cc) * 128));                                     \
         }                                                                                         \
@@ -705,13 +728,13 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
 #define WG_STAGE_A(buf, i)                                                                        \
     {                                                                                             \
         const int e = tid + 512 * (i);                                                            \
-        if (FULL || e < FP * 8)                                                                   \
+        if (FULL || e < QP * 8)                                                                   \
             *reinterpret_cast<float4 *>(smem + (buf) * 2 * PANEL + (e >> 3) * LDSW + (e & 7) * 4) = ra[i]; \
     }
 #define WG_STAGE_B(buf, i)                                                                        \
     {                                                                                             \
         const int e = tid + 512 * (i);                                                            \
-        if (FULL || e < FP * 8) {                                                                 \
+        if (FULL || e < QP * 8) {                                                                 \
             float4 h;                                                                             \
             h.x = brief_fast_sinf(om * rb[i].x); h.y = brief_fast_sinf(om * rb[i].y);             \
             h.z = brief_fast_sinf(om * rb[i].z); h.w = brief_fast_sinf(om * rb[i].w);             \
@@ -742,20 +765,20 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
                 for (int i = 0; i < TM; ++i) {
                     const int mt = wmk * TM + i;
                     af[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (MEX || mt < NT) af[i] = *reinterpret_cast<const float4 *>(As + (32 * mt + ln) * LDSW + 8 * gq + 4 * hi);
+                    if (MEX || mt < QT) af[i] = *reinterpret_cast<const float4 *>(As + (32 * mt + ln) * LDSW + 8 * gq + 4 * hi);
                     if (wnk == 0) dbacc[i] += (af[i].x + af[i].y) + (af[i].z + af[i].w);
                 }
 #pragma unroll
                 for (int jn = 0; jn < TN; ++jn) {
                     const int nt = wnk * TN + jn;
                     bf[jn] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (NEX || nt < NT) bf[jn] = *reinterpret_cast<const float4 *>(Bs + (32 * nt + ln) * LDSW + 8 * gq + 4 * hi);
+                    if (NEX || nt < QT) bf[jn] = *reinterpret_cast<const float4 *>(Bs + (32 * nt + ln) * LDSW + 8 * gq + 4 * hi);
                 }
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
 #pragma unroll
                     for (int jn = 0; jn < TN; ++jn) {
-                        if ((MEX || wmk * TM + i < NT) && (NEX || wnk * TN + jn < NT)) {
+                        if ((MEX || wmk * TM + i < QT) && (NEX || wnk * TN + jn < QT)) {
                             acc[i][jn] = MFMA(af[i].x, bf[jn].x, acc[i][jn]);
                             acc[i][jn] = MFMA(af[i].y, bf[jn].y, acc[i][jn]);
                             acc[i][jn] = MFMA(af[i].z, bf[jn].z, acc[i][jn]);
@@ -823,19 +846,19 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int mt = wmk * TM + i;
-        if (mt < NT) {
+        if (mt < QT) {
 #pragma unroll
             for (int jn = 0; jn < TN; ++jn) {
                 const int nt = wnk * TN + jn;
-                if (nt < NT) {
+                if (nt < QT) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        slab[(int64_t)(32 * mt + ROWMAP(r, hi)) * FP + 32 * nt + ln] = acc[i][jn][r];
+                        slab[(int64_t)(qm * QP + 32 * mt + ROWMAP(r, hi)) * FP + qn * QP + 32 * nt + ln] = acc[i][jn][r];
                 }
             }
-            if (wnk == 0) {
+            if (wnk == 0 && qn == 0) {
                 const float tot = dbacc[i] + __shfl_xor(dbacc[i], 32);
-                if (hi == 0) slab[(int64_t)FP * FP + 32 * mt + ln] = tot;
+                if (hi == 0) slab[(int64_t)FP * FP + qm * QP + 32 * mt + ln] = tot;
             }
         }
     }
@@ -948,7 +971,7 @@ __global__ __launch_bounds__(256) void k_reduce(const ReduceArgs a, int nb_hidde
     if (item > l0_count + head_count) return;
     int slot, wmo = 0;
     if (item == l0_count + head_count) {
-        slot = 516;                                   // loss (waves with wm == 0)
+        slot = BRIEF_REC_LOSS;                        // loss (waves with wm == 0)
     } else if (item < l0_count) {
         int o, c;
         if (item < (int64_t)F * cin) { o = (int)(item / cin); c = (int)(item % cin); }
@@ -959,10 +982,10 @@ __global__ __launch_bounds__(256) void k_reduce(const ReduceArgs a, int nb_hidde
         const int64_t r = item - l0_count;
         if (r < (int64_t)cout * F) {
             const int c = (int)(r / F), o = (int)(r % F);
-            slot = 256 + c * 64 + ((o >> 5) / WM) * 32 + (o & 31);
+            slot = BRIEF_REC_DWH + c * 128 + ((o >> 5) / WM) * 32 + (o & 31);
             wmo = (o >> 5) % WM;
         } else {
-            slot = 512 + (int)(r - (int64_t)cout * F);
+            slot = BRIEF_REC_DBH + (int)(r - (int64_t)cout * F);
         }
     }
     // record index of (wg, ws) for this wm: (wg*4 + ws*WM + wmo); enumerate q = wg*WS + ws
@@ -1193,7 +1216,7 @@ static int check_desc(const brief_siren_desc *d)
     if (d->cout < 1 || d->cout > 4) return fail(BRIEF_ERR_INVALID, "data_channel must be 1..4");
     if (d->layers < 2) return fail(BRIEF_ERR_INVALID, "layers must be >= 2");
     if (d->features < 1 || d->features > 32 * BRIEF_MAX_NT)
-        return fail(BRIEF_ERR_INVALID, "features must be 1..256 on the fused fp32 path");
+        return fail(BRIEF_ERR_INVALID, "features must be 1..512 on the fused fp32 path");
     return 0;
 }
 
@@ -1228,7 +1251,7 @@ static int fused_grid(const brief_siren_desc &d, int64_t n, bool train)
     (void)train;
     const int nt = brief_nt(d);
     const int64_t tiles = (n + brief_wg_samples(nt) - 1) / brief_wg_samples(nt);
-    const int64_t cap = (int64_t)kCUs * g_wg_per_cu;
+    const int64_t cap = (int64_t)kCUs * (nt > 8 ? 1 : g_wg_per_cu);      // >8 tiles: 512-register kernel, one workgroup per CU
     return (int)(tiles < cap ? (tiles > 0 ? tiles : 1) : cap);
 }
 static int wgrad_splits(const brief_siren_desc &d, int64_t n)
@@ -1236,7 +1259,7 @@ static int wgrad_splits(const brief_siren_desc &d, int64_t n)
     const int hidden = d.layers - 2;
     if (hidden <= 0) return 0;
     const int64_t nchunks = brief_npad(brief_nt(d), n) / 32;
-    int64_t s = kWgradBlocks / hidden;
+    int64_t s = kWgradBlocks / (hidden * wgrad_nq(brief_nt(d)) * wgrad_nq(brief_nt(d)));
     if (s < 1) s = 1;
     if (s > nchunks) s = nchunks;
     return (int)s;
@@ -1305,7 +1328,7 @@ static int launch_fused(const FusedArgs &fa, int grid, hipStream_t st)
     }
     switch (nt) {
         BRIEF_CASE(1) BRIEF_CASE(2) BRIEF_CASE(3) BRIEF_CASE(4)
-        BRIEF_CASE(5) BRIEF_CASE(6) BRIEF_CASE(7) BRIEF_CASE(8)
+        BRIEF_CASE(5) BRIEF_CASE(6) BRIEF_CASE(7) BRIEF_CASE(8) BRIEF_CASE(12) BRIEF_CASE(16)
     default: return fail(BRIEF_ERR_INVALID, "unsupported width");
     }
 #undef BRIEF_CASE
@@ -1363,6 +1386,8 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
     if (int rc = check_batch(d, grid, batch, true)) return rc;
     if (!packed || !grads || !loss_out || !workspace) return fail(BRIEF_ERR_INVALID, "null buffer");
     if (loss_kind != BRIEF_LOSS_L2 && loss_kind != BRIEF_LOSS_SMOOTHL1) return fail(BRIEF_ERR_INVALID, "bad loss_kind");
+    if ((int64_t)32 * brief_nt(*d) * brief_npad(brief_nt(*d), batch->n) * 4 >= ((int64_t)1 << 31))
+        return fail(BRIEF_ERR_INVALID, "batch too large for one train step (padded width x samples x 4 bytes must stay below 2 GiB): split it");
     const WsLayout wl = ws_layout(*d, batch->n);
     if (workspace_bytes < wl.total * (int64_t)sizeof(float)) return fail(BRIEF_ERR_WORKSPACE, "workspace too small");
     hipStream_t st = (hipStream_t)stream;
@@ -1395,14 +1420,14 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
         memset(&wa, 0, sizeof(wa));
         wa.d = *d; wa.Z = fa.Z; wa.D = fa.D; wa.npad = fa.npad; wa.nsplit = nsplit; wa.slabs = ws + wl.slabs;
         wa.stamps = ws + wl.rec + (int64_t)kCUs * 4 * 4 * BRIEF_REC_FLOATS - 256 * 8 * 8;   // tail of the record region (diagnostics)
-        const int blocks = nsplit * (d->layers - 2);
+        const int blocks = nsplit * (d->layers - 2) * wgrad_nq(nt) * wgrad_nq(nt);
 #define BRIEF_CASE(NTV)                                                                                    \
     case NTV:                                                                                              \
         hipLaunchKernelGGL((k_wgrad<NTV>), dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(NTV), st, wa); \
         break;
         switch (nt) {
             BRIEF_CASE(1) BRIEF_CASE(2) BRIEF_CASE(3) BRIEF_CASE(4)
-            BRIEF_CASE(5) BRIEF_CASE(6) BRIEF_CASE(7) BRIEF_CASE(8)
+            BRIEF_CASE(5) BRIEF_CASE(6) BRIEF_CASE(7) BRIEF_CASE(8) BRIEF_CASE(12) BRIEF_CASE(16)
         }
 #undef BRIEF_CASE
         HIP_TRY(hipGetLastError());

@@ -10,8 +10,13 @@
 #define BL_HD static inline
 #endif
 
-#define BRIEF_MAX_NT 8          // features <= 256
-#define BRIEF_REC_FLOATS 528    // per-wave partial record written by the fused kernel
+#define BRIEF_MAX_NT 16         // features <= 512 (widths above 256 are padded to 384 or 512)
+// per-wave partial record of the fused kernel: dW0[128 local features][4] | dWh[4][128] | dbh[4] | loss | stamps
+#define BRIEF_REC_FLOATS 1056
+#define BRIEF_REC_DWH 512
+#define BRIEF_REC_DBH 1024
+#define BRIEF_REC_LOSS 1028
+#define BRIEF_REC_STAMPS 1030
 
 // --- canonical parameter buffer: W0[F,cin] b0[F] | (W_l[F,F] b_l[F]) x (L-2) | Wh[cout,F] bh[cout]
 BL_HD int64_t brief_canon_hidden_off(const brief_siren_desc &d, int l /*1..L-2*/)
@@ -37,7 +42,13 @@ BL_HD int64_t brief_canon_count(const brief_siren_desc &d)
 //     bp [FP]
 //   Whp [4][FP]  (rows >= cout zero),  bhp[4]
 //   (lane = 32*hi + i ; this is the operand order of v_mfma_f32_32x32x2_f32, see brief_hip.hip)
-BL_HD int brief_nt(const brief_siren_desc &d) { return (d.features + 31) / 32; }
+// number of 32-feature tiles the width is padded to: exact up to 8 tiles, then 12 or 16 (only those
+// kernel instantiations exist above 256 features)
+BL_HD int brief_nt(const brief_siren_desc &d)
+{
+    const int nt = (d.features + 31) / 32;
+    return nt <= 8 ? nt : (nt <= 12 ? 12 : 16);
+}
 BL_HD int64_t brief_pk_w0(const brief_siren_desc &) { return 0; }
 BL_HD int64_t brief_pk_hidden_stride(const brief_siren_desc &d)
 {

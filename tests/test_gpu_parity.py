@@ -51,7 +51,8 @@ def test_forward_golden(golden, tag):
 
 
 @pytest.mark.parametrize("L,F,cin,cout,n", [(2, 16, 3, 1, 100), (3, 33, 3, 1, 31), (4, 96, 2, 3, 1000), (5, 130, 3, 1, 257),
-                                             (6, 200, 3, 1, 65), (3, 224, 3, 3, 1), (5, 256, 3, 1, 4097), (9, 64, 3, 1, 513)])
+                                             (6, 200, 3, 1, 65), (3, 224, 3, 3, 1), (5, 256, 3, 1, 4097), (9, 64, 3, 1, 513),
+                                             (4, 300, 3, 1, 200), (3, 512, 3, 1, 100), (9, 512, 3, 1, 257)])
 def test_forward_shapes_vs_oracle(L, F, cin, cout, n):
     m, d, p = make_net(L, F, 20.0, cin, cout, seed=L * 100 + F)
     x = np.random.default_rng(F).uniform(-1, 1, size=(n, cin)).astype(np.float32)
@@ -100,7 +101,8 @@ def test_loss_grads_golden(golden, tag):
 
 @pytest.mark.parametrize("L,F,cin,cout,n,oa", [(2, 16, 3, 1, 100, False), (3, 33, 3, 1, 31, False), (4, 96, 2, 3, 1000, False),
                                                 (5, 130, 3, 1, 2500, False), (6, 200, 3, 1, 650, False), (3, 224, 3, 3, 1, False),
-                                                (5, 256, 3, 1, 9000, False), (9, 64, 3, 1, 513, False), (4, 48, 3, 1, 777, True)])
+                                                (5, 256, 3, 1, 9000, False), (9, 64, 3, 1, 513, False), (4, 48, 3, 1, 777, True),
+                                                (4, 300, 3, 1, 700, False), (3, 512, 2, 3, 300, False), (5, 512, 3, 1, 1500, False)])
 def test_train_step_shapes_vs_oracle(L, F, cin, cout, n, oa):
     m, d, p = make_net(L, F, 20.0, cin, cout, oa, seed=L * 10 + F)
     rng = np.random.default_rng(F + n)
@@ -253,7 +255,7 @@ def test_sample_indices_and_sse():
 
 def test_errors_are_loud():
     L = _lib.lib()
-    d = _lib.SirenDesc(3, 1, 5, 300, 20.0, 30.0, 0, 0)
+    d = _lib.SirenDesc(3, 1, 5, 600, 20.0, 30.0, 0, 0)
     assert L.brief_packed_count(C.byref(d)) == -1
     m, _, _ = make_net(3, 16, 20.0)
     with pytest.raises(_lib.BriefError):
@@ -286,7 +288,7 @@ def test_deblock_vs_oracle_and_golden(golden):
         assert np.array_equal(deblock_volume(tt, bn, mode=mode).cpu().numpy(), O.deblock(blocky, bn, mode=mode)), mode
 
 
-@pytest.mark.parametrize("L,F,name", [(5, 256, "Adamax"), (4, 40, "Adam"), (3, 96, "SGD"), (2, 20, "Adamax")])
+@pytest.mark.parametrize("L,F,name", [(5, 256, "Adamax"), (4, 40, "Adam"), (3, 96, "SGD"), (2, 20, "Adamax"), (4, 400, "Adamax")])
 def test_fit_step_equals_separate_calls(L, F, name):
     """brief_siren_fit_step (reduce + optimizer + packed write-through fused) is bit-identical to
     train_step + optim_step + repack, parameters AND the fragment-ordered copy."""

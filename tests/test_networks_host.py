@@ -72,5 +72,8 @@ def test_capi_exports_and_sizes():
     assert L.brief_param_count(C.byref(d)) == 198657
     assert L.brief_packed_count(C.byref(d)) == 256 * 4 + 3 * (2 * 256 * 256 + 256) + 4 * 256 + 4
     assert L.brief_train_workspace_bytes(C.byref(d), 100000) > 6 * 256 * 100000 * 4
-    bad = _lib.SirenDesc(3, 1, 5, 512, 20.0, 30.0, 0, 0)
+    wide = _lib.SirenDesc(3, 1, 9, 512, 20.0, 30.0, 0, 0)
+    assert L.brief_param_count(C.byref(wide)) == 1841153          # BASELINE config 3 network (8x512)
+    assert L.brief_packed_count(C.byref(_lib.SirenDesc(3, 1, 5, 300, 20.0, 30.0, 0, 0))) == 384 * 4 + 3 * (2 * 384 * 384 + 384) + 4 * 384 + 4
+    bad = _lib.SirenDesc(3, 1, 5, 513, 20.0, 30.0, 0, 0)
     assert L.brief_param_count(C.byref(bad)) == -1 and b"features" in L.brief_last_error()

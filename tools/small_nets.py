@@ -21,3 +21,5 @@ def run(L, F, dims, sampler, n):
 run(3, 64, (64, 64, 64), 'full', 0)
 run(5, 22, (64, 64, 64), 'full', 0)
 run(7, 56, (64, 256, 256), 'randompoint', 100000)
+run(9, 512, (128, 128, 128), 'randompoint', 100000)
+run(5, 256, (256, 256, 256), 'randompoint', 100000)
