@@ -20,7 +20,7 @@ extern "C" {
 
 typedef enum {
     BRIEF_OK = 0,
-    BRIEF_ERR_INVALID = -1,      /* bad argument / unsupported configuration (e.g. res=True, F > 256) */
+    BRIEF_ERR_INVALID = -1,      /* bad argument / unsupported configuration (e.g. res=True, F > 512) */
     BRIEF_ERR_LAUNCH = -2,       /* HIP launch / runtime error */
     BRIEF_ERR_WORKSPACE = -3     /* workspace too small */
 } brief_status;
@@ -31,7 +31,7 @@ typedef struct {
     int32_t cin;         /* 2 | 3 */
     int32_t cout;        /* 1 .. 4 */
     int32_t layers;      /* >= 2 */
-    int32_t features;    /* 1 .. 256 (padded to a multiple of 32 internally) */
+    int32_t features;    /* 1 .. 512 (padded internally to a multiple of 32 up to 256, then to 384 or 512) */
     float w0_first;
     float w0_hidden;
     int32_t output_act;
