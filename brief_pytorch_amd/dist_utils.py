@@ -29,6 +29,8 @@ def assign_blocks(costs, world):
 def allreduce_sse(sse, count, device):
     """sum [sse_0..sse_k, count] over ranks (float64, exact for integer-valued SSE < 2^53)"""
     dist, _, _ = dist_info()
+    if dist is not None and dist.get_backend() == "gloo":
+        device = "cpu"
     t = torch.tensor(list(sse) + [float(count)], dtype=torch.float64, device=device)
     if dist is not None:
         dist.all_reduce(t)

@@ -52,7 +52,8 @@ def main(argv=None):
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+        # "nccl" is RCCL on ROCm; BRIEF_DIST_BACKEND=gloo rehearses the multi-rank path when ranks share a GPU
+        dist.init_process_group(os.environ.get("BRIEF_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo"))
     opt = config.load(args.p)
     log_opt = dict(opt.Log)
     if world > 1:

@@ -111,3 +111,39 @@ def test_cli_singletask_end_to_end(tmp_path, monkeypatch):
     assert os.path.exists(os.path.join(run, "steps150", "compressed", "module", "weight-0-21-3")) or \
         any(f.startswith("weight-0-") for f in os.listdir(os.path.join(run, "steps150", "compressed", "module")))
     assert os.path.exists(os.path.join(run, "performance.csv"))
+
+
+def test_cli_dividetask_two_ranks(tmp_path):
+    """DivideTask under torch.distributed with 2 ranks (sharing this box's GPU, gloo for the reductions):
+    blocks are split over the ranks, PSNR comes from the all-reduced [SSE, n], rank 0 merges and writes."""
+    import subprocess
+    import sys
+    opt = config.load(os.path.join(ROOT, "opt", "DivideTask", "default.yaml"))
+    opt.Dataset.data_path = str(tmp_path / "dataset" / "synthetic_16x48x64.tif")
+    cf = opt.CompressFramework
+    cf.Compress.divide.divide_type = "total_1_2_2"
+    cf.Compress.divide.param_alloc = "by_size"
+    cf.Compress.max_steps = 120
+    cf.Compress.checkpoints = "none"
+    cf.Compress.param.filesize_ratio = 0
+    cf.Compress.param.given_size = 24000
+    cf.Module.phi.layers = 4
+    opt.Log.outputs_dir = str(tmp_path / "outputs")
+    y = str(tmp_path / "div.yaml")
+    config.save(opt, y)
+    env = dict(os.environ, BRIEF_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "main.py"), "-p", y]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "steps 120" in r.stdout and "psnr" in r.stdout
+    run = os.path.join(str(tmp_path / "outputs"), "divide")
+    cdir = os.path.join(run, "steps120", "compressed")
+    assert len(os.listdir(os.path.join(cdir, "module"))) == 4
+    merged = read_img(os.path.join(run, "steps120", "decompressed", "synthetic_16x48x64_decompressed.tif"))
+    vol = read_img(opt.Dataset.data_path)
+    d = merged.astype(np.float64) - vol.astype(np.float64)
+    psnr = -10 * np.log10((d * d).mean() / 65535.0 ** 2)
+    import csv
+    rows = list(csv.DictReader(open(os.path.join(run, "performance.csv"))))
+    assert abs(float(rows[-1]["psnr"]) - psnr) < 1e-6 and psnr > 20
