@@ -51,7 +51,7 @@ def main(argv=None):
     from brief_pytorch_amd.framework import NFGR, MyLogger
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
         # "nccl" is RCCL on ROCm; BRIEF_DIST_BACKEND=gloo rehearses the multi-rank path when ranks share a GPU
         dist.init_process_group(os.environ.get("BRIEF_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo"))
     opt = config.load(args.p)

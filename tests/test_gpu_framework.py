@@ -135,6 +135,9 @@ def test_cli_dividetask_two_ranks(tmp_path):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29533", os.path.join(ROOT, "main.py"), "-p", y]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    if r.returncode != 0:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        open(os.path.join(ROOT, "gpurun_out", "divide2_stderr.log"), "w").write(r.stdout + "\n----\n" + r.stderr)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert "steps 120" in r.stdout and "psnr" in r.stdout
     run = os.path.join(str(tmp_path / "outputs"), "divide")
