@@ -9,11 +9,12 @@ additive noise on an offset that mimics the shipped sample's range
 """
 import numpy as np
 
-__all__ = ["make_volume"]
+__all__ = ["make_volume", "make_vessel_volume", "make_volume_torch", "ensure_dataset"]
 
 
 def make_volume(shape, seed=42, dtype=np.uint16, n_waves=8, n_blobs=32, n_tubes=16,
-                noise_sigma=200.0, base=16000.0, span=8000.0, slab=16):
+                noise_sigma=200.0, base=16000.0, span=8000.0, slab=16,
+                wave_gain=0.35, blob_gain=0.25, tube_gain=0.5, floor=0.5):
     """Return a (d, h, w, 1) volume of `dtype` (the reference's 3-D layout,
     utils/tool.py:73-92: tif stacks are read as (d,h,w) and get a channel axis)."""
     d, h, w = (int(s) for s in shape)
@@ -42,10 +43,10 @@ def make_volume(shape, seed=42, dtype=np.uint16, n_waves=8, n_blobs=32, n_tubes=
         f = np.zeros((z1 - z0, h, w), dtype=np.float64)
         for k in range(n_waves):
             f += amps[k] * np.sin(2 * np.pi * (freqs[k, 0] * z + freqs[k, 1] * y + freqs[k, 2] * x) + phases[k])
-        f = 0.5 + 0.35 * f
+        f = floor + wave_gain * f
         for k in range(n_blobs):
             r2 = (z - bc[k, 0]) ** 2 + (y - bc[k, 1]) ** 2 + (x - bc[k, 2]) ** 2
-            f += ba[k] * 0.25 * np.exp(-r2 / (2 * br[k] ** 2))
+            f += ba[k] * blob_gain * np.exp(-r2 / (2 * br[k] ** 2))
         for k in range(n_tubes):
             a, b = t0[k], t1[k]
             ab = b - a
@@ -53,7 +54,7 @@ def make_volume(shape, seed=42, dtype=np.uint16, n_waves=8, n_blobs=32, n_tubes=
             tt = ((z - a[0]) * ab[0] + (y - a[1]) * ab[1] + (x - a[2]) * ab[2]) / den
             tt = np.clip(tt, 0.0, 1.0)
             r2 = (z - (a[0] + tt * ab[0])) ** 2 + (y - (a[1] + tt * ab[1])) ** 2 + (x - (a[2] + tt * ab[2])) ** 2
-            f += ta[k] * 0.5 * np.exp(-r2 / (2 * tr[k] ** 2))
+            f += ta[k] * tube_gain * np.exp(-r2 / (2 * tr[k] ** 2))
         # per-slab noise stream keyed by (seed, z0) so slab size does not change the volume
         nrng = np.random.default_rng([seed, z0 // slab, 7])
         v = base + span * f + nrng.normal(0.0, noise_sigma, size=f.shape)
@@ -63,10 +64,22 @@ def make_volume(shape, seed=42, dtype=np.uint16, n_waves=8, n_blobs=32, n_tubes=
     return out
 
 
-def make_volume_torch(shape, seed=42, device="cuda", n_waves=8, n_blobs=32, noise_sigma=200.0, base=16000.0, span=8000.0, slab=32):
+def make_vessel_volume(shape, seed=42, dtype=np.uint16):
+    """Sparse, vessel-like variant (BASELINE config 5: the shape of the reference's
+    dataset/example/vessel-0_64-0_512-0_512.tif): dark, nearly flat background, ~5 % bright tubular
+    foreground, little noise — the statistics `adaptotal`/`by_var` budgeting is meant for."""
+    return make_volume(shape, seed=seed, dtype=dtype, n_waves=3, n_blobs=6, n_tubes=32, noise_sigma=60.0,
+                       base=1200.0, span=9000.0, wave_gain=0.02, blob_gain=0.05, tube_gain=3.0, floor=0.05)
+
+
+def make_volume_torch(shape, seed=42, device="cuda", n_waves=8, n_blobs=32, noise_sigma=200.0, base=16000.0, span=8000.0, slab=32,
+                      detail=0, detail_fmax=64.0, detail_gain=0.6):
     """Same kind of field as make_volume, generated on the device slab by slab (512^3 in about a
     second) for the benchmark volumes.  Returns a uint16 torch tensor (d, h, w, 1).  The field
-    parameters come from numpy's generator so they do not depend on the torch build."""
+    parameters come from numpy's generator so they do not depend on the torch build.
+    `detail` > 0 adds that many oriented sinusoids with |f| log-uniform in [6, detail_fmax] cycles and
+    amplitude ~ 1/|f| (a 1/f texture): the plain field is fitted down to its noise floor by any net, the
+    textured one makes PSNR depend on the bitrate (tools/rate_distortion.py)."""
     import torch
     d, h, w = (int(s) for s in shape)
     rng = np.random.default_rng(seed)
@@ -77,6 +90,15 @@ def make_volume_torch(shape, seed=42, device="cuda", n_waves=8, n_blobs=32, nois
     bc = rng.uniform(0, 1, size=(n_blobs, 3)).astype(np.float32)
     br = rng.uniform(0.03, 0.12, size=n_blobs).astype(np.float32)
     ba = rng.uniform(0.2, 0.9, size=n_blobs).astype(np.float32)
+    if detail:
+        drng = np.random.default_rng([seed, 99])
+        dmag = np.exp(drng.uniform(np.log(6.0), np.log(detail_fmax), size=detail))
+        ddir = drng.normal(size=(detail, 3))
+        ddir /= np.linalg.norm(ddir, axis=1, keepdims=True)
+        dfreq = (ddir * dmag[:, None]).astype(np.float32)
+        dph = drng.uniform(0, 2 * np.pi, size=detail).astype(np.float32)
+        damp = (1.0 / dmag)
+        damp = (detail_gain * damp / np.sqrt((damp ** 2).sum())).astype(np.float32)
     out = torch.empty((d, h, w, 1), dtype=torch.uint16, device=device)
     y = (torch.arange(h, device=device, dtype=torch.float32) / max(h - 1, 1))[None, :, None]
     x = (torch.arange(w, device=device, dtype=torch.float32) / max(w - 1, 1))[None, None, :]
@@ -88,6 +110,8 @@ def make_volume_torch(shape, seed=42, device="cuda", n_waves=8, n_blobs=32, nois
         for k in range(n_waves):
             f += float(amps[k]) * torch.sin(6.283185307179586 * (float(freqs[k, 0]) * z + float(freqs[k, 1]) * y + float(freqs[k, 2]) * x) + float(phases[k]))
         f = 0.5 + 0.35 * f
+        for k in range(detail):
+            f += float(damp[k]) * torch.sin(6.283185307179586 * (float(dfreq[k, 0]) * z + float(dfreq[k, 1]) * y + float(dfreq[k, 2]) * x) + float(dph[k]))
         for k in range(n_blobs):
             r2 = (z - float(bc[k, 0])) ** 2 + (y - float(bc[k, 1])) ** 2 + (x - float(bc[k, 2])) ** 2
             f += float(ba[k]) * 0.25 * torch.exp(-r2 / (2 * float(br[k]) ** 2))
@@ -98,20 +122,21 @@ def make_volume_torch(shape, seed=42, device="cuda", n_waves=8, n_blobs=32, nois
 
 
 def ensure_dataset(path):
-    """`dataset/synthetic_<n>.tif` (or `synthetic_<d>x<h>x<w>.tif`) is generated on first use; any other
-    missing path is an error.  The reference's sample volumes are not redistributed here."""
+    """`dataset/synthetic_<n>.tif`, `synthetic_<d>x<h>x<w>.tif` and `synthetic_vessel_<d>x<h>x<w>.tif` are
+    generated on first use; any other missing path is an error.  The reference's sample volumes are not
+    redistributed here."""
     import os
     import re
     if os.path.exists(path):
         return path
-    m = re.fullmatch(r"synthetic_(\d+)(?:x(\d+)x(\d+))?\.tiff?", os.path.basename(path))
+    m = re.fullmatch(r"synthetic_(vessel_)?(\d+)(?:x(\d+)x(\d+))?\.tiff?", os.path.basename(path))
     if not m:
         raise FileNotFoundError(path)
-    d = int(m.group(1))
-    shape = (d, int(m.group(2)), int(m.group(3))) if m.group(2) else (d, d, d)
+    d = int(m.group(2))
+    shape = (d, int(m.group(3)), int(m.group(4))) if m.group(3) else (d, d, d)
     from .tool import save_img
     os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
-    save_img(path, make_volume(shape, seed=42))
+    save_img(path, (make_vessel_volume if m.group(1) else make_volume)(shape, seed=42))
     return path
 
 

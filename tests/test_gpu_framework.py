@@ -92,6 +92,36 @@ def test_dividetask_single_rank(tmp_path):
     assert abs(-10 * np.log10((d * d).mean() / 65535.0 ** 2) - res[200]["psnr"]) < 1e-6
 
 
+def test_dividetask_vessel_shaped(tmp_path):
+    """BASELINE config 5 in small: opt/DivideTask/vessel.yaml (adaptotal, <= 4 blocks sized by cal_divide_num,
+    by_size budget, 7-layer nets, w0 = 10) on a 16x128x128 vessel-like stack, 400 steps."""
+    opt = config.load(os.path.join(ROOT, "opt", "DivideTask", "vessel.yaml"))
+    from brief_pytorch_amd.synthetic import ensure_dataset
+    path = ensure_dataset(str(tmp_path / "dataset" / "synthetic_vessel_16x128x128.tif"))
+    vol = read_img(path)
+    assert vol.shape == (16, 128, 128, 1) and 0.02 < (vol > 4000).mean() < 0.12      # sparse foreground
+    cf = opt.CompressFramework
+    cf.Compress.max_steps = 400
+    cf.Compress.checkpoints = "none"
+    cf.Compress.param.filesize_ratio = 32
+    opt.Log.outputs_dir = str(tmp_path / "outputs")
+    opt.Log.time = False
+    Log = MyLogger(**opt.Log)
+    torch.manual_seed(42)
+    fw = NFGR(cf, Log=Log)
+    res = fw.compress_divide(path, opt)
+    cdir = os.path.join(Log.logdir, "steps400", "compressed")
+    names = sorted(os.listdir(os.path.join(cdir, "module")))
+    assert 1 <= len(names) <= 4
+    feats = [config.load(os.path.join(cdir, "sideinfos", n, "sideinfos.yaml"))["phi_features"] for n in names]
+    total = sum(SIREN.calc_param_count(3, 1, f, 7) for f in feats) * 4
+    assert abs(total - vol.size * 2 / 32) / (vol.size * 2 / 32) < 0.08            # the blocks share the ratio-32 budget
+    assert res[400]["psnr"] > 27                                                   # sanity floor after 400 steps (29.7 measured)
+    merged = read_img(os.path.join(Log.logdir, "steps400", "decompressed", "synthetic_vessel_16x128x128_decompressed.tif"))
+    d = merged.astype(np.float64) - vol.astype(np.float64)
+    assert abs(-10 * np.log10((d * d).mean() / 65535.0 ** 2) - res[400]["psnr"]) < 1e-6
+
+
 def test_cli_singletask_end_to_end(tmp_path, monkeypatch):
     """python main.py -p <yaml>: the drop-in CLI on a generated 24x32x40 volume (randomcube -> full batch)"""
     import subprocess
