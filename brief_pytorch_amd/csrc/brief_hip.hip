@@ -57,7 +57,16 @@ struct GridArgs {
     int64_t dims[3];
     float lo, hi;
     float step[3];
+    int fast;               // the grid has fewer than 2^32 points: 32-bit indices, division by multiplication
+    uint64_t magic[3];      // floor(2^64 / dims[a]) + 1   (exact quotients for every 32-bit numerator)
 };
+
+// n / dv for a loop-invariant divisor (Lemire's fastdiv: one 64-bit multiply-high instead of ~100 VALU
+// instructions of 64-bit division; the VALU is what the f32 MFMA competes with)
+__device__ __forceinline__ uint32_t fast_div(uint32_t nn, uint64_t magic, uint32_t dv)
+{
+    return dv == 1 ? nn : (uint32_t)__umul64hi(magic, (uint64_t)nn);
+}
 
 struct FusedArgs {
     brief_siren_desc d;
@@ -76,6 +85,7 @@ struct FusedArgs {
     float *D;            // [(L-2)][FP][npad]   deltas of layers 1..L-2
     int64_t npad;
     float *rec;          // [gridDim.x*4][BRIEF_REC_FLOATS]
+    float *slabs;        // k_small only: [(L-2)][gridDim.x][FP*FP + FP] per-workgroup hidden-layer gradient partials
     float *yhat_out;     // [n][cout] or NULL
     void *out;           // forward output
     int out_kind;
@@ -101,6 +111,50 @@ __device__ __forceinline__ float lin_coord(const GridArgs &g, int a, int64_t i)
     const int64_t nn = g.dims[a];
     if (nn == 1) return g.lo;
     return i < nn / 2 ? __fmaf_rn(g.step[a], (float)i, g.lo) : __fmaf_rn(-g.step[a], (float)(nn - 1 - i), g.hi);
+}
+
+__device__ __forceinline__ float lin_coord32(const GridArgs &g, int a, uint32_t i)
+{
+    const uint32_t nn = (uint32_t)g.dims[a];
+    if (nn == 1) return g.lo;
+    return i < nn / 2 ? __fmaf_rn(g.step[a], (float)i, g.lo) : __fmaf_rn(-g.step[a], (float)(nn - 1 - i), g.hi);
+}
+
+// voxel index -> coordinates of the flattened (d,h,w) / (h,w) grid (create_flattened_coords, utils/dataset.py:36-62)
+__device__ __forceinline__ void grid_coords(const GridArgs &g, int cin, int64_t j, float &x0, float &x1, float &x2)
+{
+    if (cin == 3) {
+        int64_t id, ih, iw;
+        if (g.fast) {
+            const uint32_t ju = (uint32_t)j, d2 = (uint32_t)g.dims[2], d1 = (uint32_t)g.dims[1];
+            const uint32_t t2 = fast_div(ju, g.magic[2], d2);
+            const uint32_t t1 = fast_div(t2, g.magic[1], d1);
+            x0 = lin_coord32(g, 0, t1);
+            x1 = lin_coord32(g, 1, t2 - t1 * d1);
+            x2 = lin_coord32(g, 2, ju - t2 * d2);
+            return;
+        } else {
+            iw = j % g.dims[2];
+            const int64_t t2 = j / g.dims[2];
+            ih = t2 % g.dims[1]; id = t2 / g.dims[1];
+        }
+        x0 = lin_coord(g, 0, id);
+        x1 = lin_coord(g, 1, ih);
+        x2 = lin_coord(g, 2, iw);
+    } else {
+        int64_t ih, iw;
+        if (g.fast) {
+            const uint32_t ju = (uint32_t)j, d1 = (uint32_t)g.dims[1];
+            const uint32_t t1 = fast_div(ju, g.magic[1], d1);
+            x0 = lin_coord32(g, 0, t1);
+            x1 = lin_coord32(g, 1, ju - t1 * d1);
+            return;
+        } else {
+            iw = j % g.dims[1]; ih = j / g.dims[1];
+        }
+        x0 = lin_coord(g, 0, ih);
+        x1 = lin_coord(g, 1, iw);
+    }
 }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -309,16 +363,8 @@ __global__ __launch_bounds__(256, TRAIN ? (NT > 8 ? 1 : BRIEF_TRAIN_WPE) : (NT >
                 x0 = a.coords[j * cin];
                 x1 = a.coords[j * cin + 1];
                 if (cin == 3) x2 = a.coords[j * cin + 2];
-            } else if (cin == 3) {
-                const int64_t iw = j % a.grid.dims[2], t2 = j / a.grid.dims[2];
-                const int64_t ih = t2 % a.grid.dims[1], id = t2 / a.grid.dims[1];
-                x0 = lin_coord(a.grid, 0, id);
-                x1 = lin_coord(a.grid, 1, ih);
-                x2 = lin_coord(a.grid, 2, iw);
             } else {
-                const int64_t iw = j % a.grid.dims[1], ih = j / a.grid.dims[1];
-                x0 = lin_coord(a.grid, 0, ih);
-                x1 = lin_coord(a.grid, 1, iw);
+                grid_coords(a.grid, cin, j, x0, x1, x2);
             }
         }
         f32x16 acc[K::MTW];
@@ -630,6 +676,410 @@ __global__ __launch_bounds__(256, TRAIN ? (NT > 8 ? 1 : BRIEF_TRAIN_WPE) : (NT >
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_small<NT, HB>: the whole train step of a NARROW net (F <= 64: NT = 1, 2; at most HB hidden F x F layers)
+// without any HBM stash.  For these widths (every net the reference's own YAMLs produce: F = 22 ... 56) the
+// stash traffic of k_fused + k_wgrad, not the matrix pipe, sets the step time (1.8 KB per sample against
+// 9 kFLOP), so here everything stays on chip:
+//   * the pre-activations z_l of every sine layer stay in registers (16 per layer: a wave owns one 32x32 tile),
+//     sin / cos are recomputed from them on the way back;
+//   * the weight gradients accumulate in registers across all tiles a workgroup walks: delta_l and h_{l-1}
+//     are transposed through LDS ([feature][sample] panels, stride 36 floats, conflict-free ds_read_b128) into
+//     A / B operands whose k index is the sample, 16 MFMAs per (32x32 dW tile, 32 samples);
+//   * NT = 1: the 4 waves are independent (own samples, own LDS regions, no barriers in the tile loop) and
+//     fold their dW at the end;  NT = 2: wave (wm, ws) owns dW tile (wm, ws) over both sample tiles;
+//   * one slab per workgroup and layer goes to k_reduce (same slab format as k_wgrad's).
+// inputs of sample n for the train kernels: coordinates, targets, loss weights (defaults past the end of the batch)
+__device__ __forceinline__ void small_inputs(const FusedArgs &a, int cin, int cout, int64_t n, float4 &xo, float4 &yo, float4 &wo)
+{
+    float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+    float yv[4] = {0.f, 0.f, 0.f, 0.f}, wv4[4] = {1.f, 1.f, 1.f, 1.f};
+    if (n < a.n) {
+        const int64_t j = a.idx ? a.idx[n] : (a.rng_pop ? philox_index(n, a.rng_pop, a.rng_seed, a.rng_step) : n + a.offset);
+        if (cout == 1) {
+            yv[0] = a.targets[j];
+            if (a.weights) wv4[0] = a.weights[j];
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (c < cout) {
+                    yv[c] = a.targets[j * cout + c];
+                    if (a.weights) wv4[c] = a.weights[j * cout + c];
+                }
+            }
+        }
+        if (a.coords) {
+            x0 = a.coords[j * cin];
+            x1 = a.coords[j * cin + 1];
+            if (cin == 3) x2 = a.coords[j * cin + 2];
+        } else {
+            grid_coords(a.grid, cin, j, x0, x1, x2);
+        }
+    }
+    xo = make_float4(x0, x1, x2, 0.f);
+    yo = make_float4(yv[0], yv[1], yv[2], yv[3]);
+    wo = make_float4(wv4[0], wv4[1], wv4[2], wv4[3]);
+}
+
+template <int NT>
+struct SmallLds {
+    using K = KCfg<NT>;
+    static constexpr int PANEL = 32 * 36;
+    static constexpr int DT_OFF = K::XS_FLOATS;           // delta^T panels, one per wave
+    static constexpr int HT_OFF = DT_OFF + 4 * PANEL;     // h^T panels, one per wave
+    static constexpr int G_OFF = HT_OFF + 4 * PANEL;
+    static constexpr int HW_OFF = G_OFF + 4 * 256;
+    static constexpr int TOTAL = HW_OFF + 4 * K::FP + 4;
+};
+constexpr int small_wpe(int HB) { return HB <= 3 ? 2 : 1; }     // resident workgroups per CU (register budget)
+
+template <int NT, int HB>
+__global__ __launch_bounds__(256, small_wpe(HB)) void k_small(const FusedArgs a)
+{
+    static_assert(NT == 1 || NT == 2, "narrow nets only");
+#ifdef BRIEF_STAMPS
+    float st_acc[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    long long st_last = clock64();
+#endif
+    using K = KCfg<NT>;
+    using LD = SmallLds<NT>;
+    constexpr int PANEL = LD::PANEL;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float4 *X = reinterpret_cast<float4 *>(smem);
+    float *DT = smem + LD::DT_OFF, *HT = smem + LD::HT_OFF;
+    float *G = smem + LD::G_OFF;
+    float *HW = smem + LD::HW_OFF;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hi = lane >> 5, ln = lane & 31;
+    const int wm = wave % K::WM, ws = wave / K::WM;
+    const brief_siren_desc &d = a.d;
+    const int L = d.layers, cin = d.cin, cout = d.cout;
+    const float *pk = a.pk;
+    float4 *Xs = X + ws * (NT * 256);
+    float *DTw = DT + wave * PANEL, *HTw = HT + wave * PANEL;
+    float *Gw = G + wave * 256;
+    const float4 *W0p = reinterpret_cast<const float4 *>(pk + brief_pk_w0(d));
+    const __amdgpu_buffer_rsrc_t rs_pk =
+        __builtin_amdgcn_make_buffer_rsrc((void *)pk, 0, (int)(brief_pk_count(d) * 4), 0x00020000);
+    // NT == 1: every LDS region is private to its wave and a wave's LDS operations complete in order
+#define TILE_BARRIER() { if (NT > 1) lds_barrier(); else asm volatile("" ::: "memory"); }
+
+    {
+        const float *headp = pk + brief_pk_head(d);
+        for (int e = threadIdx.x; e < 4 * K::FP + 4; e += 256) HW[e] = headp[e];
+    }
+    lds_barrier();
+
+    f32x16 dW[HB];
+    float dbv[HB];
+#pragma unroll
+    for (int i = 0; i < HB; ++i) {
+        dbv[i] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dW[i][r] = 0.f;
+    }
+    // skinny gradients: lane (ln, hi) <-> feature ln of the own tile, samples 16 hi .. 16 hi + 15
+    float acc0[4] = {0.f, 0.f, 0.f, 0.f}, accWh[4] = {0.f, 0.f, 0.f, 0.f}, accbh[4] = {0.f, 0.f, 0.f, 0.f};
+    float lsum = 0.f;
+    const int prow = ln * 36 + 16 * hi;      // this lane's 16 samples of row ln in a panel
+
+    const int64_t wg_samples = 32 * K::WS;
+    const int64_t ntiles = (a.n + wg_samples - 1) / wg_samples;
+    // (measured and not kept: fetching the next tile's inputs, or the next chain's first A fragments, one
+    //  phase ahead costs more in registers -> scratch than the latency it hides)
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t n0 = (tile * K::WS + ws) * 32;
+        const int64_t n = n0 + ln;
+        const bool valid = n < a.n;
+        float4 in_x, in_y, in_w;     // coords (x0,x1,x2,-) | targets | loss weights
+        small_inputs(a, cin, cout, n, in_x, in_y, in_w);
+        const float x0 = in_x.x, x1 = in_x.y, x2 = in_x.z;
+        const float yv[4] = {in_y.x, in_y.y, in_y.z, in_y.w}, wv4[4] = {in_w.x, in_w.y, in_w.z, in_w.w};
+        f32x16 acc[1], hreg[1];
+        f32x16 zst[HB + 1];
+        float4 bnext[4];
+
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bnext[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        // ---- layer 0 (two K=2 MFMAs against [x0 x1 | x2 1], bias folded in)
+        {
+            const float4 w = W0p[32 * wm + ln];
+            acc[0] = MFMA(hi ? w.y : w.x, hi ? x1 : x0, acc[0]);
+            acc[0] = MFMA(hi ? w.w : w.z, hi ? 1.0f : x2, acc[0]);
+        }
+        STAMP(0)
+        // ---- sine layers 0 .. L-2 (unrolled to the bucket size so that zst[] stays in registers)
+#pragma unroll
+        for (int l = 0; l <= HB; ++l) {
+            if (l <= L - 2) {
+                const float om = l == 0 ? d.w0_first : d.w0_hidden;
+                const bool last = (l == L - 2);
+                if (l > 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        acc[0][4 * q] = bnext[q].x; acc[0][4 * q + 1] = bnext[q].y;
+                        acc[0][4 * q + 2] = bnext[q].z; acc[0][4 * q + 3] = bnext[q].w;
+                    }
+                    chain<NT>(acc, rs_pk, (int)(brief_pk_hidden(d, l) * 4), Xs, wm, lane);
+                    STAMP(1)
+                    TILE_BARRIER()
+                }
+                if (!last) {
+                    const float *bp_ = pk + brief_pk_hidden(d, l + 1) + 2 * K::FP * K::FP;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bnext[q] = *reinterpret_cast<const float4 *>(bp_ + 32 * wm + 8 * q + 4 * hi);
+                }
+                zst[l] = acc[0];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hreg[0][r] = BRIEF_SIN_REV(brief_revolutions(om * acc[0][r]));
+                write_image<NT>(Xs, hreg, wm, lane);
+                TILE_BARRIER()
+                STAMP(2)
+            }
+        }
+        // ---- head
+        float zo[4], yh[4], g[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            zo[c] = 0.f; yh[c] = 0.f; g[c] = 0.f;
+            if (c < cout) {
+                float p = 0.f;
+                const float *wrow = HW + c * K::FP;
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 hv = Xs[(kt * 4 + q) * 64 + lane];
+                        const float4 wv = *reinterpret_cast<const float4 *>(wrow + 32 * kt + 8 * q + 4 * hi);
+                        p = __fmaf_rn(wv.x, hv.x, p); p = __fmaf_rn(wv.y, hv.y, p);
+                        p = __fmaf_rn(wv.z, hv.z, p); p = __fmaf_rn(wv.w, hv.w, p);
+                    }
+                }
+                p += __shfl_xor(p, 32);
+                zo[c] = p + HW[4 * K::FP + c];
+                yh[c] = d.output_act ? brief_fast_sinf(d.w0_hidden * zo[c]) : zo[c];
+            }
+        }
+        // ---- loss and dloss/dyhat (main.py:176-191)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c < cout && valid) {
+                float we = wv4[c];
+                if (a.thr != 0.f && yh[c] <= a.thr) we = 1.0f;
+                const float df = yh[c] - yv[c];
+                float li, gi;
+                if (a.loss_kind == BRIEF_LOSS_L2) { li = df * df; gi = 2.0f * df; }
+                else {
+                    const float ad = fabsf(df);
+                    if (ad < a.beta) { li = 0.5f * df * df / a.beta; gi = df / a.beta; }
+                    else { li = ad - 0.5f * a.beta; gi = df < 0.f ? -1.0f : 1.0f; }
+                }
+                if (wm == 0 && hi == 0) lsum += li * we;
+                g[c] = gi * we * a.inv_count;
+                if (d.output_act) g[c] *= d.w0_hidden * brief_fast_cosf(d.w0_hidden * zo[c]);
+                if (a.yhat_out && wm == 0 && hi == 0) a.yhat_out[n * cout + c] = yh[c];
+            }
+        }
+        // ---- head gradients from the transposed last activation
+#pragma unroll
+        for (int r = 0; r < 16; ++r) HTw[ROWMAP(r, hi) * 36 + ln] = hreg[0][r];
+        if (hi == 0) *reinterpret_cast<float4 *>(Gw + ln * 4) = make_float4(g[0], g[1], g[2], g[3]);
+        else *reinterpret_cast<float4 *>(Gw + 128 + ln * 4) = make_float4(x0, x1, x2, 1.0f);
+        TILE_BARRIER()      // also: every wave is past its head reads of the image
+        if (cout == 1) {
+            float sW = 0.f, sb = 0.f;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const float4 hv = *reinterpret_cast<const float4 *>(HTw + prow + 4 * q4);
+                const float hvv[4] = {hv.x, hv.y, hv.z, hv.w};
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const float gv = Gw[(16 * hi + 4 * q4 + jj) * 4];
+                    sW = __fmaf_rn(hvv[jj], gv, sW);
+                    sb += gv;
+                }
+            }
+            accWh[0] += sW;
+            accbh[0] += sb;
+        } else {
+            float4 sW = make_float4(0.f, 0.f, 0.f, 0.f), sb = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const float4 hv = *reinterpret_cast<const float4 *>(HTw + prow + 4 * q4);
+                const float hvv[4] = {hv.x, hv.y, hv.z, hv.w};
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const float4 gv = *reinterpret_cast<const float4 *>(Gw + (16 * hi + 4 * q4 + jj) * 4);
+                    sW.x = __fmaf_rn(hvv[jj], gv.x, sW.x); sW.y = __fmaf_rn(hvv[jj], gv.y, sW.y);
+                    sW.z = __fmaf_rn(hvv[jj], gv.z, sW.z); sW.w = __fmaf_rn(hvv[jj], gv.w, sW.w);
+                    sb.x += gv.x; sb.y += gv.y; sb.z += gv.z; sb.w += gv.w;
+                }
+            }
+            accWh[0] += sW.x; accWh[1] += sW.y; accWh[2] += sW.z; accWh[3] += sW.w;
+            accbh[0] += sb.x; accbh[1] += sb.y; accbh[2] += sb.z; accbh[3] += sb.w;
+        }
+        STAMP(3)
+        // ---- Wh^T g: the last sine layer's delta is c_{L-2} times this (taken inside the unrolled loop below,
+        //      where the layer index is a compile-time constant and z comes straight out of its registers)
+        f32x16 dl[1];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (c < cout) {
+                    const float4 wv = *reinterpret_cast<const float4 *>(HW + c * K::FP + 32 * wm + 8 * q + 4 * hi);
+                    sacc.x = __fmaf_rn(wv.x, g[c], sacc.x); sacc.y = __fmaf_rn(wv.y, g[c], sacc.y);
+                    sacc.z = __fmaf_rn(wv.z, g[c], sacc.z); sacc.w = __fmaf_rn(wv.w, g[c], sacc.w);
+                }
+            }
+            dl[0][4 * q] = sacc.x; dl[0][4 * q + 1] = sacc.y; dl[0][4 * q + 2] = sacc.z; dl[0][4 * q + 3] = sacc.w;
+        }
+#define SMALL_TOP_DELTA(layer)                                                                           \
+    if ((layer) == L - 2) {                                                                              \
+        const float omt = (layer) == 0 ? d.w0_first : d.w0_hidden;                                       \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                   \
+            dl[0][r] *= omt * BRIEF_COS_REV(brief_revolutions(omt * zst[(layer)][r]));                   \
+    }
+        // ---- backward through the hidden layers L-2 .. 1: dW_l += delta_l h_{l-1}^T, delta_{l-1} = (W_l^T delta_l) . c_{l-1}
+#pragma unroll
+        for (int li = HB; li >= 1; --li) {
+            SMALL_TOP_DELTA(li)
+            if (li <= L - 2) {
+                const float om1 = (li - 1) == 0 ? d.w0_first : d.w0_hidden;
+                f32x16 cp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float fr = brief_revolutions(om1 * zst[li - 1][r]);
+                    HTw[ROWMAP(r, hi) * 36 + ln] = BRIEF_SIN_REV(fr);
+                    cp[r] = om1 * BRIEF_COS_REV(fr);
+                    DTw[ROWMAP(r, hi) * 36 + ln] = dl[0][r];
+                }
+                write_image<NT>(Xs, dl, wm, lane);
+                TILE_BARRIER()
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+                STAMP(4)
+                chain<NT>(acc, rs_pk, (int)((brief_pk_hidden(d, li) + K::FP * K::FP) * 4), Xs, wm, lane);
+                STAMP(5)
+                // weight gradient: k = sample; lane (m, hi) feeds samples 16 hi + s at step s
+#pragma unroll
+                for (int st = 0; st < K::WS; ++st) {
+                    if (NT == 1 && st != ws) continue;       // NT == 1: only the wave's own sample tile
+                    const float *pa = (NT == 1 ? DTw : DT + (st * K::WM + wm) * PANEL) + prow;
+                    const float *pb = (NT == 1 ? HTw : HT + (st * K::WM + ws) * PANEL) + prow;
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const float4 a4 = *reinterpret_cast<const float4 *>(pa + 4 * q4);
+                        const float4 b4 = *reinterpret_cast<const float4 *>(pb + 4 * q4);
+                        dW[li - 1] = MFMA(a4.x, b4.x, dW[li - 1]);
+                        dW[li - 1] = MFMA(a4.y, b4.y, dW[li - 1]);
+                        dW[li - 1] = MFMA(a4.z, b4.z, dW[li - 1]);
+                        dW[li - 1] = MFMA(a4.w, b4.w, dW[li - 1]);
+                        dbv[li - 1] += (a4.x + a4.y) + (a4.z + a4.w);
+                    }
+                }
+                STAMP(6)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dl[0][r] = acc[0][r] * cp[r];
+                TILE_BARRIER()      // panels and image are rewritten by the next layer
+            }
+        }
+        SMALL_TOP_DELTA(0)
+#undef SMALL_TOP_DELTA
+        // ---- first-layer gradients from delta_0
+#pragma unroll
+        for (int r = 0; r < 16; ++r) DTw[ROWMAP(r, hi) * 36 + ln] = dl[0][r];
+        TILE_BARRIER()
+        {
+            float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const float4 dv = *reinterpret_cast<const float4 *>(DTw + prow + 4 * q4);
+                const float dvv[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const float4 xv = *reinterpret_cast<const float4 *>(Gw + 128 + (16 * hi + 4 * q4 + jj) * 4);
+                    s0.x = __fmaf_rn(dvv[jj], xv.x, s0.x); s0.y = __fmaf_rn(dvv[jj], xv.y, s0.y);
+                    s0.z = __fmaf_rn(dvv[jj], xv.z, s0.z); s0.w = __fmaf_rn(dvv[jj], xv.w, s0.w);
+                }
+            }
+            acc0[0] += s0.x; acc0[1] += s0.y; acc0[2] += s0.z; acc0[3] += s0.w;
+        }
+        TILE_BARRIER()
+        STAMP(7)
+    }
+#undef TILE_BARRIER
+    // ---- per-wave record of the skinny gradients (format of k_fused: k_reduce reads both)
+    {
+        float *rec = a.rec + ((int64_t)blockIdx.x * 4 + wave) * BRIEF_REC_FLOATS;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float v0 = acc0[c] + __shfl_xor(acc0[c], 32);
+            const float vh = accWh[c] + __shfl_xor(accWh[c], 32);
+            const float vb = accbh[c] + __shfl_xor(accbh[c], 32);
+            if (hi == 0) {
+                rec[ln * 4 + c] = v0;
+                rec[BRIEF_REC_DWH + c * 128 + ln] = vh;
+            }
+            if (lane == 0) rec[BRIEF_REC_DBH + c] = vb;
+        }
+        for (int off = 32; off >= 1; off >>= 1) lsum += __shfl_xor(lsum, off);
+        if (lane == 0) rec[BRIEF_REC_LOSS] = lsum;
+#ifdef BRIEF_STAMPS
+        if (lane == 0) for (int i = 0; i < 10; ++i) rec[BRIEF_REC_STAMPS + i] = st_acc[i];
+#endif
+    }
+    // ---- hidden-layer partials: one slab per (layer, workgroup)
+    const int64_t slab_sz = (int64_t)K::FP * K::FP + K::FP;
+    if (NT == 2) {
+#pragma unroll
+        for (int i = 0; i < HB; ++i) {
+            if (i < L - 2) {
+                float *slab = a.slabs + ((int64_t)i * gridDim.x + blockIdx.x) * slab_sz;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) slab[(32 * wm + ROWMAP(r, hi)) * K::FP + 32 * ws + ln] = dW[i][r];
+                const float tot = dbv[i] + __shfl_xor(dbv[i], 32);
+                if (ws == 0 && hi == 0) slab[K::FP * K::FP + 32 * wm + ln] = tot;
+            }
+        }
+    } else {
+        // fold the four waves' partial tiles in wave order (the tile loop's LDS regions are dead now)
+        float *red = smem, *redb = smem + 3 * 1024;
+        lds_barrier();
+#pragma unroll
+        for (int i = 0; i < HB; ++i) {
+            if (i < L - 2) {
+                if (wave > 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[(wave - 1) * 1024 + r * 64 + lane] = dW[i][r];
+                    redb[(wave - 1) * 64 + lane] = dbv[i];
+                }
+                lds_barrier();
+                if (wave == 0) {
+                    f32x16 tsum = dW[i];
+                    float bsum = dbv[i];
+                    for (int w = 1; w < 4; ++w) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) tsum[r] += red[(w - 1) * 1024 + r * 64 + lane];
+                        bsum += redb[(w - 1) * 64 + lane];
+                    }
+                    float *slab = a.slabs + ((int64_t)i * gridDim.x + blockIdx.x) * slab_sz;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) slab[ROWMAP(r, hi) * K::FP + ln] = tsum[r];
+                    const float tot = bsum + __shfl_xor(bsum, 32);
+                    if (hi == 0) slab[K::FP * K::FP + ln] = tot;
+                }
+                lds_barrier();
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // weight-gradient GEMM: dW_l[fo][fi] = sum_n D_l[fo][n] * sin(w Z_{l-1}[fi][n]),  db_l = sum_n D_l
 struct WgradArgs {
     brief_siren_desc d;
@@ -907,6 +1357,7 @@ struct ReduceArgs {
     int nrec_wg;
     const float *slabs;
     int nsplit;
+    int sgroups;          // hidden parameters: threads per parameter (1 for k_wgrad's <= 85 slabs, 8 for k_small's one per workgroup)
     float *grads;
     float *loss_out;
     float inv_count;
@@ -935,20 +1386,34 @@ __global__ __launch_bounds__(256) void k_reduce(const ReduceArgs a, int nb_hidde
     const int64_t off_head = brief_canon_head_off(d);
     const int64_t l0_count = (int64_t)F * cin + F;
     if ((int)blockIdx.x < nb_hidden) {
+        // sgroups threads per parameter: thread (pl, sg) adds slabs sg, sg + sgroups, ...; group 0 then adds the
+        // group sums in group order (fixed order: bit-reproducible)
+        __shared__ float fold[256];
         const int64_t hcount = off_head - l0_count;
-        const int64_t hidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-        if (hidx >= hcount) return;
+        const int SG = a.sgroups, ppb = 256 / SG;
+        const int pl = threadIdx.x % ppb, sg = threadIdx.x / ppb;
+        const int64_t hidx = (int64_t)blockIdx.x * ppb + pl;
+        const bool live = hidx < hcount;
         const int64_t per = (int64_t)F * F + F;
-        const int l = 1 + (int)(hidx / per);
-        const int64_t r = hidx % per;
-        int64_t so;
-        if (r < (int64_t)F * F) so = (r / F) * FP + (r % F);
-        else so = (int64_t)FP * FP + (r - (int64_t)F * F);
-        const int64_t slab_sz = (int64_t)FP * FP + FP;
-        const float *base = a.slabs + (int64_t)(l - 1) * a.nsplit * slab_sz + so;
+        const int l = live ? 1 + (int)(hidx / per) : 1;
+        const int64_t r = live ? hidx % per : 0;
         float s = 0.f;
+        if (live) {
+            int64_t so;
+            if (r < (int64_t)F * F) so = (r / F) * FP + (r % F);
+            else so = (int64_t)FP * FP + (r - (int64_t)F * F);
+            const int64_t slab_sz = (int64_t)FP * FP + FP;
+            const float *base = a.slabs + (int64_t)(l - 1) * a.nsplit * slab_sz + so;
 #pragma unroll 8
-        for (int sp = 0; sp < a.nsplit; ++sp) s += base[(int64_t)sp * slab_sz];
+            for (int sp = sg; sp < a.nsplit; sp += SG) s += base[(int64_t)sp * slab_sz];
+        }
+        if (SG > 1) {
+            fold[threadIdx.x] = s;
+            __syncthreads();
+            if (sg == 0)
+                for (int gq = 1; gq < SG; ++gq) s += fold[gq * ppb + pl];
+        }
+        if (!live || sg != 0) return;
         a.grads[l0_count + hidx] = s;
         if (a.update) {
             const float pv = optim_apply(a.opt, s, a.params, a.s1, a.s2, l0_count + hidx);
@@ -1265,17 +1730,39 @@ static int wgrad_splits(const brief_siren_desc &d, int64_t n)
     return (int)s;
 }
 
+// narrow nets (F <= 64, at most 7 hidden layers) train through k_small: no stash, no k_wgrad.
+// BRIEF_SMALL=0 (diagnostics) sends them down the general k_fused + k_wgrad path instead.
+static bool use_small(const brief_siren_desc &d)
+{
+    static int enabled = -1;
+    if (enabled < 0) { const char *e = getenv("BRIEF_SMALL"); enabled = (e && atoi(e) == 0) ? 0 : 1; }
+    return enabled && brief_nt(d) <= 2 && d.layers - 2 <= 7;
+}
+static int small_hb(const brief_siren_desc &d)
+{
+    const int h = d.layers - 2;
+    return h <= 1 ? 1 : (h <= 3 ? 3 : (h <= 5 ? 5 : 7));
+}
+static int small_grid(const brief_siren_desc &d, int64_t n)
+{
+    const int nt = brief_nt(d);
+    const int64_t tiles = (n + brief_wg_samples(nt) - 1) / brief_wg_samples(nt);
+    const int64_t cap = (int64_t)kCUs * small_wpe(small_hb(d));
+    return (int)(tiles < cap ? (tiles > 0 ? tiles : 1) : cap);
+}
+
 struct WsLayout { int64_t z, dd, rec, slabs, total; };
 static WsLayout ws_layout(const brief_siren_desc &d, int64_t n)
 {
     const int nt = brief_nt(d);
     const int64_t FP = 32 * nt, npad = brief_npad(nt, n), hidden = d.layers - 2 > 0 ? d.layers - 2 : 0;
+    const bool small = use_small(d);
     WsLayout w;
     w.z = 0;
-    w.dd = w.z + hidden * FP * npad;
-    w.rec = w.dd + hidden * FP * npad;
+    w.dd = w.z + (small ? 0 : hidden * FP * npad);
+    w.rec = w.dd + (small ? 0 : hidden * FP * npad);
     w.slabs = w.rec + (int64_t)kCUs * 4 /*max wg/CU*/ * 4 * BRIEF_REC_FLOATS;
-    w.total = w.slabs + hidden * (int64_t)wgrad_splits(d, n) * (FP * FP + FP);
+    w.total = w.slabs + hidden * (int64_t)(small ? small_grid(d, n) : wgrad_splits(d, n)) * (FP * FP + FP);
     return w;
 }
 
@@ -1310,10 +1797,14 @@ static void fill_grid(GridArgs &g, const brief_grid_desc *grid)
     if (!grid) return;
     g.ndim = grid->ndim;
     g.lo = grid->lo; g.hi = grid->hi;
+    double total = 1.0;
     for (int a = 0; a < 3; ++a) {
         g.dims[a] = a < grid->ndim ? grid->dims[a] : 1;
         g.step[a] = g.dims[a] > 1 ? (grid->hi - grid->lo) / (float)(g.dims[a] - 1) : 0.f;
+        g.magic[a] = ~(uint64_t)0 / (uint64_t)g.dims[a] + 1;
+        total *= (double)g.dims[a];
     }
+    g.fast = total < 4294967296.0;
 }
 
 template <bool TRAIN>
@@ -1395,8 +1886,9 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
     const int nt = brief_nt(*d);
     if (const char *e = getenv("BRIEF_WG_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 4) g_wg_per_cu = v; }
     if (const char *e = getenv("BRIEF_STAGGER")) g_stagger = atoi(e);
-    const int grid1 = fused_grid(*d, batch->n, true);
-    const int nsplit = wgrad_splits(*d, batch->n);
+    const bool small = use_small(*d);
+    const int grid1 = small ? small_grid(*d, batch->n) : fused_grid(*d, batch->n, true);
+    const int nsplit = small ? (d->layers > 2 ? grid1 : 0) : wgrad_splits(*d, batch->n);
     const float inv_count = (float)(1.0 / ((double)batch->n * d->cout));
 
     FusedArgs fa;
@@ -1408,14 +1900,23 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
     fill_grid(fa.grid, grid);
     fa.loss_kind = loss_kind; fa.thr = thr; fa.beta = beta; fa.inv_count = inv_count;
     fa.Z = ws + wl.z; fa.D = ws + wl.dd; fa.npad = brief_npad(nt, batch->n);
-    fa.rec = ws + wl.rec; fa.yhat_out = yhat_out;
+    fa.rec = ws + wl.rec; fa.slabs = ws + wl.slabs; fa.yhat_out = yhat_out;
     fa.stagger_cus = kCUs; fa.stagger = g_stagger;
     const bool prof = g_prof_on && g_prof_n < kProfSlots;
     if (prof) HIP_TRY(hipEventRecord(g_prof_ev[2 * g_prof_n], st));
-    if (int rc = launch_fused<true>(fa, grid1, st)) return rc;
+    if (small) {
+        const int hb = small_hb(*d);
+#define BRIEF_CASE(NTV, HBV)                                                                                        \
+    if (nt == NTV && hb == HBV)                                                                                     \
+        hipLaunchKernelGGL((k_small<NTV, HBV>), dim3(grid1), dim3(256), sizeof(float) * SmallLds<NTV>::TOTAL, st, fa);
+        BRIEF_CASE(1, 1) BRIEF_CASE(1, 3) BRIEF_CASE(1, 5) BRIEF_CASE(1, 7)
+        BRIEF_CASE(2, 1) BRIEF_CASE(2, 3) BRIEF_CASE(2, 5) BRIEF_CASE(2, 7)
+#undef BRIEF_CASE
+        HIP_TRY(hipGetLastError());
+    } else if (int rc = launch_fused<true>(fa, grid1, st)) return rc;
     if (prof) { HIP_TRY(hipEventRecord(g_prof_ev[2 * g_prof_n + 1], st)); ++g_prof_n; }
 
-    if (nsplit > 0) {
+    if (!small && nsplit > 0) {
         WgradArgs wa;
         memset(&wa, 0, sizeof(wa));
         wa.d = *d; wa.Z = fa.Z; wa.D = fa.D; wa.npad = fa.npad; wa.nsplit = nsplit; wa.slabs = ws + wl.slabs;
@@ -1435,12 +1936,14 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
     ReduceArgs ra;
     memset(&ra, 0, sizeof(ra));
     ra.d = *d; ra.rec = fa.rec; ra.nrec_wg = grid1; ra.slabs = ws + wl.slabs; ra.nsplit = nsplit;
+    ra.sgroups = small ? 8 : 1;
     ra.grads = grads; ra.loss_out = loss_out; ra.inv_count = inv_count;
     if (upd) { ra.update = 1; ra.opt = upd->opt; ra.params = upd->params; ra.s1 = upd->s1; ra.s2 = upd->s2; ra.pk = upd->pk; }
     const int64_t l0_count = (int64_t)d->features * d->cin + d->features;
     const int64_t hcount = brief_canon_head_off(*d) - l0_count;
     const int64_t skinny = l0_count + (int64_t)d->cout * d->features + d->cout + 1;   // + the loss
-    const int nb_hidden = (int)((hcount + 255) / 256);
+    const int ppb = 256 / ra.sgroups;                  // hidden parameters per k_reduce block
+    const int nb_hidden = (int)((hcount + ppb - 1) / ppb);
     const int nb_skinny = (int)((skinny + 3) / 4);
     hipLaunchKernelGGL(k_reduce, dim3(nb_hidden + nb_skinny), dim3(256), 0, st, ra, nb_hidden);
     HIP_TRY(hipGetLastError());

@@ -116,6 +116,29 @@ def test_train_step_shapes_vs_oracle(L, F, cin, cout, n, oa):
     _check_grads(m, d, go)
 
 
+@pytest.mark.parametrize("L,F,cin,cout,n", [(2, 8, 3, 1, 33), (3, 22, 3, 1, 4000), (4, 32, 2, 3, 129), (5, 22, 3, 1, 70000), (6, 17, 3, 1, 555),
+                                             (7, 30, 3, 2, 3000), (8, 9, 3, 1, 64), (9, 32, 3, 1, 2049), (3, 64, 3, 1, 50000), (4, 35, 3, 1, 1000),
+                                             (5, 56, 2, 1, 40000), (6, 40, 3, 4, 200), (7, 56, 3, 1, 66000), (8, 64, 3, 1, 321), (9, 33, 3, 1, 1500),
+                                             (10, 24, 3, 1, 500), (11, 48, 3, 1, 500)])
+def test_narrow_nets_on_chip_path_vs_oracle(L, F, cin, cout, n):
+    """F <= 64 nets train through k_small (no stash; z in registers, dW accumulated in registers across the
+    persistent tile loop): every (tile count, hidden-layer bucket) combination, ragged batches, enough samples
+    that a workgroup walks several tiles; layers > 9 take the general path.  Same oracle, same tolerance."""
+    m, d, p = make_net(L, F, 20.0, cin, cout, False, seed=L * 100 + F)
+    rng = np.random.default_rng(F * 7 + n)
+    x = rng.uniform(-1, 1, size=(n, cin)).astype(np.float32)
+    y = rng.uniform(0, 100, size=(n, cout)).astype(np.float32)
+    w = np.where(rng.uniform(size=(n, cout)) < 0.5, 0.25, 1.0).astype(np.float32)
+    args = dict(coords=torch.from_numpy(x).to(DEV), weights=torch.from_numpy(w).to(DEV), thr=30.0)
+    loss, _ = m.train_step(n, torch.from_numpy(y).to(DEV), **args)
+    g1 = m.grads.clone()
+    lo, go, _, _ = O.loss_grad(d, p, x, y, w, 0, 30.0, 0.01)
+    assert abs(loss.item() - lo) / abs(lo) < 1e-5
+    _check_grads(m, d, go)
+    loss2, _ = m.train_step(n, torch.from_numpy(y).to(DEV), **args)
+    assert torch.equal(g1, m.grads) and loss.item() == loss2.item()      # fixed summation order: bit-reproducible
+
+
 def test_train_step_is_deterministic_and_batch_split_linear():
     """Property tests at a larger size: two launches give identical bits (no atomics), and the
     gradient of a batch is the count-weighted sum of the gradients of its two halves."""

@@ -1,4 +1,4 @@
-"""scratch: small-net regime timing (C1 2x64 full batch 64^3, C5-like 7x56 randompoint)"""
+"""scratch: small-net regime timing (C1 2x64 full batch 64^3, default.yaml 5x22, C5-like 7x56 randompoint)"""
 import sys, torch
 sys.path.insert(0, '.')
 from brief_pytorch_amd.fit import Fitter
@@ -18,8 +18,12 @@ def run(L, F, dims, sampler, n):
     ms = e0.elapsed_time(e1) / 50
     M = 3 * F + (L - 2) * F * F + F
     print("L=%d F=%d n=%d: %.3f ms/step %.1f Msamples/s %.1f TFLOP/s" % (L, F, fit.n, ms, fit.n / ms / 1e3, 2 * (3 * M - 3 * F) * fit.n / ms / 1e9), flush=True)
+big = len(sys.argv) > 1 and sys.argv[1] == 'all'
 run(3, 64, (64, 64, 64), 'full', 0)
 run(5, 22, (64, 64, 64), 'full', 0)
+run(5, 35, (128, 128, 128), 'randompoint', 100000)
 run(7, 56, (64, 256, 256), 'randompoint', 100000)
-run(9, 512, (128, 128, 128), 'randompoint', 100000)
-run(5, 256, (256, 256, 256), 'randompoint', 100000)
+run(9, 30, (64, 256, 256), 'randompoint', 100000)
+if big:
+    run(9, 512, (128, 128, 128), 'randompoint', 100000)
+    run(5, 256, (256, 256, 256), 'randompoint', 100000)
