@@ -33,12 +33,24 @@ class BatchDesc(C.Structure):
                 ("offset", C.c_int64), ("n", C.c_int64), ("rng_pop", C.c_int64), ("rng_seed", C.c_uint64), ("rng_step", C.c_uint64)]
 
 
+class FitJob(C.Structure):          # brief_fit_job
+    _fields_ = [("desc", SirenDesc), ("grid", GridDesc), ("batch", BatchDesc),
+                ("params", C.c_void_p), ("packed", C.c_void_p), ("state1", C.c_void_p), ("state2", C.c_void_p),
+                ("grads", C.c_void_p), ("loss_out", C.c_void_p), ("loss_log", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+                ("loss_kind", C.c_int32), ("optim_kind", C.c_int32), ("thr", C.c_float), ("beta", C.c_float),
+                ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
+                ("milestones", C.POINTER(C.c_int64)), ("n_milestones", C.c_int32), ("reserved", C.c_int32),
+                ("gamma", C.c_double), ("t0", C.c_int64)]
+
+
 LOSS_KIND = {"datal2": 0, "datasmoothl1": 1}
 OPT_KIND = {"Adamax": 0, "Adam": 1, "SGD": 2}
 OUT_F32, OUT_U8, OUT_U16 = 0, 1, 2
 
 EXPORTS = ["brief_version", "brief_last_error", "brief_param_count", "brief_packed_count",
            "brief_train_workspace_bytes", "brief_siren_repack", "brief_siren_forward", "brief_siren_train_step", "brief_siren_fit_step",
+           "brief_siren_fit", "brief_multi_fit",
            "brief_optim_step", "brief_sample_indices", "brief_sse_u16", "brief_profile_enable", "brief_profile_fused", "brief_deblock_edge", "brief_ssim_u16", "brief_ssim_partial_count"]
 
 
@@ -90,6 +102,8 @@ def lib():
     L.brief_siren_train_step.argtypes = [dp, vp, gp, bp, C.c_int, C.c_float, C.c_float, vp, vp, vp, vp, C.c_int64, vp]
     L.brief_siren_fit_step.argtypes = [dp, vp, vp, gp, bp, C.c_int, C.c_float, C.c_float, C.c_int, vp, vp,
                                        C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64, vp, vp, vp, C.c_int64, vp]
+    L.brief_siren_fit.argtypes = [C.POINTER(FitJob), C.c_int64, vp]
+    L.brief_multi_fit.argtypes = [C.POINTER(FitJob), C.c_int32, C.c_int64, vp]
     L.brief_optim_step.argtypes = [C.c_int, vp, vp, vp, vp, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64, vp]
     L.brief_sample_indices.argtypes = [vp, C.c_int64, C.c_int64, C.c_uint64, C.c_uint64, vp]
     L.brief_sse_u16.argtypes = [vp, vp, C.c_int64, vp, vp]

@@ -1975,6 +1975,88 @@ int brief_siren_fit_step(const brief_siren_desc *d, float *params, float *packed
     return train_step_impl(d, packed, grid, batch, loss_kind, thr, beta, grads, loss_out, nullptr, workspace, workspace_bytes, stream, &up);
 }
 
+static int fit_job_check(const brief_fit_job *j)
+{
+    if (!j) return fail(BRIEF_ERR_INVALID, "null job");
+    if (j->batch.idx) return fail(BRIEF_ERR_INVALID, "a per-step index stream cannot be replayed by brief_siren_fit: use brief_siren_fit_step");
+    if (!j->params || !j->packed || !j->grads || !j->loss_out || !j->workspace) return fail(BRIEF_ERR_INVALID, "null buffer");
+    if (j->t0 < 0) return fail(BRIEF_ERR_INVALID, "bad step count");
+    if (j->n_milestones < 0 || (j->n_milestones > 0 && !j->milestones)) return fail(BRIEF_ERR_INVALID, "bad lr milestones");
+    return 0;
+}
+
+// one optimizer step (number t, 1-based) of a job on stream st; *lr is the running MultiStepLR value
+static int fit_job_step(const brief_fit_job *j, int64_t t, int64_t k, double *lr, hipStream_t st)
+{
+    // scheduler.step() calls made so far = t - 1: apply the milestones that were hit by the last one
+    if (t - 1 > j->t0) {
+        int hits = 0;
+        for (int m = 0; m < j->n_milestones; ++m) hits += (j->milestones[m] == t - 1);
+        if (hits) *lr = *lr * pow(j->gamma, (double)hits);
+    }
+    brief_batch_desc b = j->batch;
+    if (!b.idx && b.rng_pop > 0) b.rng_step = (uint64_t)t;
+    return brief_siren_fit_step(&j->desc, j->params, j->packed, &j->grid, &b, j->loss_kind, j->thr, j->beta, j->optim_kind,
+                                j->state1, j->state2, *lr, j->beta1, j->beta2, j->eps, t, j->grads,
+                                j->loss_log ? j->loss_log + k : j->loss_out, j->workspace, j->workspace_bytes, (void *)st);
+}
+
+int brief_siren_fit(const brief_fit_job *job, int64_t steps, void *stream)
+{
+    if (int rc = fit_job_check(job)) return rc;
+    if (steps < 0) return fail(BRIEF_ERR_INVALID, "bad step count");
+    double lr = job->lr;
+    for (int64_t k = 0; k < steps; ++k)
+        if (int rc = fit_job_step(job, job->t0 + 1 + k, k, &lr, (hipStream_t)stream)) return rc;
+    if (job->loss_log && steps > 0)
+        HIP_TRY(hipMemcpyAsync(job->loss_out, job->loss_log + steps - 1, sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
+static const int kPoolStreams = 8;
+static hipStream_t g_pool[kPoolStreams];
+static hipEvent_t g_pool_ev[kPoolStreams + 1];
+static bool g_pool_init = false;
+
+int brief_multi_fit(const brief_fit_job *jobs, int32_t njobs, int64_t steps, void *stream)
+{
+    if (njobs < 1 || !jobs) return fail(BRIEF_ERR_INVALID, "no jobs");
+    if (steps < 0) return fail(BRIEF_ERR_INVALID, "bad step count");
+    if (njobs > 4096) return fail(BRIEF_ERR_INVALID, "too many jobs for one call");
+    for (int j = 0; j < njobs; ++j)
+        if (int rc = fit_job_check(&jobs[j])) return rc;
+    if (njobs == 1) return brief_siren_fit(jobs, steps, stream);
+    if (!g_pool_init) {
+        for (int s = 0; s < kPoolStreams; ++s) HIP_TRY(hipStreamCreateWithFlags(&g_pool[s], hipStreamNonBlocking));
+        for (int s = 0; s <= kPoolStreams; ++s) HIP_TRY(hipEventCreateWithFlags(&g_pool_ev[s], hipEventDisableTiming));
+        g_pool_init = true;
+    }
+    hipStream_t caller = (hipStream_t)stream;
+    const int ns = njobs < kPoolStreams ? njobs : kPoolStreams;
+    // fork: everything already queued on the caller's stream happens before the first step of every job
+    HIP_TRY(hipEventRecord(g_pool_ev[kPoolStreams], caller));
+    for (int s = 0; s < ns; ++s) HIP_TRY(hipStreamWaitEvent(g_pool[s], g_pool_ev[kPoolStreams], 0));
+    double *lrs = (double *)malloc(sizeof(double) * njobs);
+    if (!lrs) return fail(BRIEF_ERR_INVALID, "out of host memory");
+    for (int j = 0; j < njobs; ++j) lrs[j] = jobs[j].lr;
+    int rc = 0;
+    // step-major order: the host feeds all streams evenly instead of running ahead on one of them
+    for (int64_t k = 0; k < steps && !rc; ++k)
+        for (int j = 0; j < njobs && !rc; ++j)
+            rc = fit_job_step(&jobs[j], jobs[j].t0 + 1 + k, k, &lrs[j], g_pool[j % ns]);
+    free(lrs);
+    for (int j = 0; j < njobs && !rc && steps > 0; ++j)
+        if (jobs[j].loss_log &&
+            hipMemcpyAsync(jobs[j].loss_out, jobs[j].loss_log + steps - 1, sizeof(float), hipMemcpyDeviceToDevice, g_pool[j % ns]) != hipSuccess)
+            rc = fail(BRIEF_ERR_LAUNCH, "hipMemcpyAsync");
+    // join (also on error: whatever was queued must be ordered before the caller's next work)
+    for (int s = 0; s < ns; ++s) {
+        HIP_TRY(hipEventRecord(g_pool_ev[s], g_pool[s]));
+        HIP_TRY(hipStreamWaitEvent(caller, g_pool_ev[s], 0));
+    }
+    return rc;
+}
+
 int brief_optim_step(int kind, float *params, const float *grads, float *state1, float *state2, int64_t count,
                      double lr, double beta1, double beta2, double eps, int64_t t, void *stream)
 {

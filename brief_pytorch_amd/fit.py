@@ -61,6 +61,47 @@ class Fitter:
         else:
             raise NotImplementedError("lr scheduler %r" % sch.get("name"))
         self.t = 0
+        self._milestones = sorted(int(v) for v in sch.get("milestones", [])) if sch.get("name") == "MultiStepLR" else []
+        self._gamma = float(sch.get("gamma", 0.1)) if self._milestones else 1.0
+        self._ms_arr = (C.c_int64 * max(len(self._milestones), 1))(*self._milestones)
+        self._keep = None
+
+    def job(self, steps, log=False):
+        """brief_fit_job for the next `steps` optimizer steps (include/brief_hip.h).  Tensors referenced by the
+        job are kept alive by this object until the next call."""
+        if self.index_stream is not None:
+            raise _lib.BriefError("a replayed index stream needs step(): brief_siren_fit draws its indices in-kernel")
+        m = self.m
+        m._require_gpu()
+        m.sync_packed()
+        m.ensure_train_buffers(self.n)
+        loss_log = torch.zeros(max(int(steps), 1), dtype=torch.float32, device=m.params.device) if log else None
+        g = m._grid(self.dims, self.range[0], self.range[1])
+        rnd = self.sampler == "randompoint"
+        b = _lib.BatchDesc(None, self.targets.data_ptr(), self.weights.data_ptr() if self.weights is not None else None, None,
+                           0, int(self.n), int(self.pop) if rnd else 0, int(self.seed) if rnd else 0, 0)
+        j = _lib.FitJob()
+        j.desc, j.grid, j.batch = m.desc, g, b
+        j.params, j.packed = m.params.data_ptr(), m.packed.data_ptr()
+        j.state1, j.state2 = self.s1.data_ptr(), self.s2.data_ptr()
+        j.grads, j.loss_out = m.grads.data_ptr(), m._loss.data_ptr()
+        j.loss_log = loss_log.data_ptr() if log else None
+        j.workspace, j.workspace_bytes = m._ws.data_ptr(), m._ws.numel() * 4
+        j.loss_kind, j.optim_kind = _lib.LOSS_KIND[self.loss_name], self.opt
+        j.thr, j.beta = self.thr, self.beta
+        j.lr, j.beta1, j.beta2, j.eps = self.lr_at(self.t + 1), 0.9, 0.999, 1e-8
+        j.milestones = C.cast(self._ms_arr, C.POINTER(C.c_int64))
+        j.n_milestones, j.gamma, j.t0 = len(self._milestones), self._gamma, self.t
+        self._keep = (loss_log, g, b)
+        return j, loss_log
+
+    def run(self, steps, log=False):
+        """`steps` optimizer steps in ONE C-ABI call (brief_siren_fit): same results, bit for bit, as calling
+        step() that many times.  Returns the device loss of the last step, or the per-step loss tensor if log."""
+        j, loss_log = self.job(steps, log)
+        _lib.check(_lib.lib().brief_siren_fit(C.byref(j), int(steps), _lib.stream_ptr()))
+        self.t += int(steps)
+        return loss_log if log else self.m._loss
 
     def step(self):
         """one optimisation step; returns the device loss tensor (no sync)."""
@@ -74,3 +115,22 @@ class Fitter:
                 rng = (self.pop, self.seed, t)      # drawn inside the fused kernel (== brief_sample_indices(pop, seed, t))
         return self.m.fit_step(self.n, self.targets, self.opt, self.s1, self.s2, self.lr_at(t), t, idx=idx, weights=self.weights,
                                grid=(self.dims, self.range[0], self.range[1]), loss=self.loss_name, thr=self.thr, beta=self.beta, rng=rng)
+
+
+class MultiFitter:
+    """Independent fits trained together on one GPU (the blocks of a DivideTask partition that one rank owns,
+    main.py:547-575): brief_multi_fit runs fitter j on internal HIP stream j mod 8, so the launches of narrow
+    nets overlap instead of leaving most CUs idle.  Every fit's results are identical to running it alone."""
+
+    def __init__(self, fitters):
+        self.fitters = list(fitters)
+
+    def run(self, steps, log=False):
+        if not self.fitters:
+            return []
+        jobs, logs = zip(*(f.job(steps, log) for f in self.fitters))
+        arr = (_lib.FitJob * len(jobs))(*jobs)
+        _lib.check(_lib.lib().brief_multi_fit(arr, len(jobs), int(steps), _lib.stream_ptr()))
+        for f in self.fitters:
+            f.t += int(steps)
+        return list(logs) if log else [f.m._loss for f in self.fitters]

@@ -142,10 +142,11 @@ class NFGR:
         return preprocess(data, pp.denoise.level, pp.denoise.close, pp.clip)
 
     # ---- SingleTask encode (main.py:322-454)
-    def compress(self, data_path, data=None, logdir=None, evaluate=True):
+    def prepare_fit(self, data_path, data=None, logdir=None):
+        """everything main.py:322-384 sets up before the loop: preprocess, loss weights, normalise, size the
+        net, put targets on the device, build the Fitter.  Returns the context the loop and the checkpoints use."""
         opt, C_ = self.opt, self.opt.Compress
-        Log = self.Log
-        logdir = logdir or Log.logdir
+        logdir = logdir or self.Log.logdir
         if data is None:
             data = read_img(data_path)
         cube = C_.sampler.cube_len
@@ -171,7 +172,6 @@ class NFGR:
         assert C_.loss.weight_thres <= get_type_max(pre), "The weight threshold should be less than the data maximum!"
         thr_t, _ = normalize_data(np.array(C_.loss.weight_thres), **opt.Normalize, max=sideinfos["max"], min=sideinfos["min"])
         thr = float(thr_t)
-        max_steps = C_.max_steps
         sampler, index_stream = "randompoint", None
         if C_.sampler.name == "randomcube":
             cl = [min(cube[i], data.shape[i]) for i in range(len(dims))]
@@ -185,8 +185,54 @@ class NFGR:
         fit = Fitter(phi, tgt, dims, _coords_range(C_.coords_mode), weights=wts, sampler=sampler, sample_size=n_step,
                      optimizer=C_.optimizer_name_phi, lr=C_.lr_phi, scheduler=config.to_plain(C_.lr_scheduler_phi),
                      loss=C_.loss.name, thr=thr, beta=C_.loss.beta, seed=getattr(opt, "_seed", 42), index_stream=index_stream)
+        self.sideinfos = sideinfos
+        return {"fit": fit, "phi": phi, "data": data, "data_path": data_path, "logdir": logdir, "name": name, "ext": ext,
+                "sideinfos": sideinfos, "theory_size": theory_size, "results": {}}
+
+    def checkpoint(self, ctx, steps, loss, evaluate=True):
+        """main.py:405-450 at one checkpoint: weight files + sideinfos, optional decode + metrics."""
+        opt, C_, Log = self.opt, self.opt.Compress, self.Log
+        data, name, ext, sideinfos = ctx["data"], ctx["name"], ctx["ext"], ctx["sideinfos"]
+        sdir = opj(ctx["logdir"], "steps{}".format(steps))
+        cdir = opj(sdir, "compressed")
+        os.makedirs(cdir, exist_ok=True)
+        module_path, side_path = opj(cdir, "module"), opj(cdir, "sideinfos.yaml")
+        save_yaml(sideinfos, side_path)
+        save_model(ctx["phi"], module_path, self.device)
+        orig_bytes = os.path.getsize(ctx["data_path"]) if os.path.exists(ctx["data_path"]) else data.nbytes
+        side_bytes = os.path.getsize(side_path)
+        if Log is not None:
+            Log.log_metrics({"compress_ratio/theory": orig_bytes / (side_bytes + ctx["theory_size"]),
+                             "compress_ratio/actual": orig_bytes / (side_bytes + get_folder_size(module_path))}, steps)
+        if C_.decompress and evaluate:
+            dec = NFGR.decompress(_wrap(opt), module_path, sideinfos, self.device)
+            if opt.Decompress.keep_decompressed:
+                ddir = opj(sdir, "decompressed")
+                os.makedirs(ddir, exist_ok=True)
+                save_img(opj(ddir, name + "_decompressed" + ext), dec)
+            if opt.Decompress.mip and data.ndim == 4:
+                mdir = opj(sdir, "mip")
+                os.makedirs(mdir, exist_ok=True)
+                for tag, vol in ((name, data), (name + "_decompressed", dec)):
+                    for ax, img in zip("dhw", mip_ops(vol)):
+                        save_img(opj(mdir, "%s_mip_%s%s" % (tag, ax, ext)), img)
+            if data.dtype == np.uint16 and data.ndim == 4 and data.shape[-1] == 1 and min(data.shape[1:3]) >= 11:
+                perf = {"steps": steps, **gpu_eval_u16(data, dec, opt.Decompress.mse, opt.Decompress.psnr, opt.Decompress.ssim)}
+                if Log is not None:
+                    Log.log_metrics({k: v for k, v in perf.items() if k != "steps"}, steps)
+            else:
+                perf = eval_performance(steps, data, dec, Log, opt.Decompress.mse, opt.Decompress.psnr, opt.Decompress.ssim)
+            perf["loss"] = float(loss.item())
+            _append_csv(opj(ctx["logdir"], "performance.csv"), perf)
+            ctx["results"][steps] = perf
+        # step directories are always kept (the reference's inverted -stepstore flag is not reproduced)
+
+    def compress(self, data_path, data=None, logdir=None, evaluate=True):
+        C_, Log = self.opt.Compress, self.Log
+        ctx = self.prepare_fit(data_path, data, logdir)
+        fit = ctx["fit"]
+        max_steps = C_.max_steps
         checkpoints = parse_checkpoints(C_.checkpoints, max_steps)
-        results = {}
         t_fit = 0.0
         for steps in range(1, max_steps + 1):
             t0 = time.perf_counter()
@@ -195,42 +241,9 @@ class NFGR:
                 Log.log_metrics({"loss": loss.item()}, steps)      # the only host sync, at log frequency
             t_fit += time.perf_counter() - t0
             if steps in checkpoints:
-                sdir = opj(logdir, "steps{}".format(steps))
-                cdir = opj(sdir, "compressed")
-                os.makedirs(cdir, exist_ok=True)
-                module_path, side_path = opj(cdir, "module"), opj(cdir, "sideinfos.yaml")
-                save_yaml(sideinfos, side_path)
-                save_model(phi, module_path, self.device)
-                orig_bytes = os.path.getsize(data_path) if os.path.exists(data_path) else data.nbytes
-                side_bytes = os.path.getsize(side_path)
-                if Log is not None:
-                    Log.log_metrics({"compress_ratio/theory": orig_bytes / (side_bytes + theory_size),
-                                     "compress_ratio/actual": orig_bytes / (side_bytes + get_folder_size(module_path))}, steps)
-                if C_.decompress and evaluate:
-                    dec = NFGR.decompress(_wrap(opt), module_path, sideinfos, self.device)
-                    if opt.Decompress.keep_decompressed:
-                        ddir = opj(sdir, "decompressed")
-                        os.makedirs(ddir, exist_ok=True)
-                        save_img(opj(ddir, name + "_decompressed" + ext), dec)
-                    if opt.Decompress.mip and data.ndim == 4:
-                        mdir = opj(sdir, "mip")
-                        os.makedirs(mdir, exist_ok=True)
-                        for tag, vol in ((name, data), (name + "_decompressed", dec)):
-                            for ax, img in zip("dhw", mip_ops(vol)):
-                                save_img(opj(mdir, "%s_mip_%s%s" % (tag, ax, ext)), img)
-                    if data.dtype == np.uint16 and data.ndim == 4 and data.shape[-1] == 1 and min(data.shape[1:3]) >= 11:
-                        perf = {"steps": steps, **gpu_eval_u16(data, dec, opt.Decompress.mse, opt.Decompress.psnr, opt.Decompress.ssim)}
-                        if Log is not None:
-                            Log.log_metrics({k: v for k, v in perf.items() if k != "steps"}, steps)
-                    else:
-                        perf = eval_performance(steps, data, dec, Log, opt.Decompress.mse, opt.Decompress.psnr, opt.Decompress.ssim)
-                    perf["loss"] = float(loss.item())
-                    _append_csv(opj(logdir, "performance.csv"), perf)
-                    results[steps] = perf
-                # step directories are always kept (the reference's inverted -stepstore flag is not reproduced)
+                self.checkpoint(ctx, steps, loss, evaluate)
         self.fit_seconds = t_fit
-        self.sideinfos = sideinfos
-        return results
+        return ctx["results"]
 
     # ---- DivideTask (main.py:484-651)
     def divide(self, data, data_path, param_size):
@@ -291,6 +304,10 @@ class NFGR:
         sse = np.zeros(len(checkpoints), np.float64)
         cnt = 0.0
         decoded = {k: [] for k in checkpoints}
+        # every block this rank owns is prepared first (nets are initialised in partition order, as a serial
+        # run would), then all of them are trained TOGETHER: brief_multi_fit spreads them over HIP streams so the
+        # launches of narrow nets overlap; the results per block are those of a fit on its own.
+        mine = []
         for i, c in enumerate(chunks):
             if owner[i] != rank:
                 continue
@@ -298,7 +315,27 @@ class NFGR:
             sub_dir = opj(logdir, "subexps", c["name"])
             os.makedirs(sub_dir, exist_ok=True)
             block = np.ascontiguousarray(c["data"])
-            sub.compress(opj(sub_dir, c["name"] + ext), data=block, logdir=sub_dir, evaluate=False)
+            mine.append((c, sub, sub_dir, block, sub.prepare_fit(opj(sub_dir, c["name"] + ext), data=block, logdir=sub_dir)))
+        cotrain = len(mine) > 1 and all(m[4]["fit"].index_stream is None for m in mine) and os.environ.get("BRIEF_COTRAIN", "1") != "0"
+        t0 = time.perf_counter()
+        if cotrain:
+            from .fit import MultiFitter
+            group = MultiFitter([m[4]["fit"] for m in mine])
+            done = 0
+            for k in checkpoints:
+                losses = group.run(k - done)
+                done = k
+                for (c, sub, sub_dir, block, ctx), loss in zip(mine, losses):
+                    sub.checkpoint(ctx, k, loss, evaluate=False)
+        else:
+            for c, sub, sub_dir, block, ctx in mine:
+                for steps in range(1, C_.max_steps + 1):
+                    loss = ctx["fit"].step()
+                    if steps in checkpoints:
+                        sub.checkpoint(ctx, steps, loss, evaluate=False)
+        torch.cuda.synchronize() if torch.cuda.is_available() else None
+        self.fit_seconds = time.perf_counter() - t0
+        for c, sub, sub_dir, block, ctx in mine:
             for ki, k in enumerate(checkpoints):
                 src = opj(sub_dir, "steps{}".format(k), "compressed")
                 mdst = opj(logdir, "steps{}".format(k), "compressed", "module", c["name"])

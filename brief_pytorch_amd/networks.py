@@ -288,15 +288,7 @@ class SIREN:
         bit-identical to the separate calls.  Returns the device loss tensor."""
         self._require_gpu()
         self.sync_packed()
-        dev = self.params.device
-        if self.grads is None:
-            self.grads = torch.zeros_like(self.params)
-            self._loss = torch.zeros(1, dtype=torch.float32, device=dev)
-        need = _lib.lib().brief_train_workspace_bytes(C.byref(self.desc), int(n))
-        if need < 0:
-            raise _lib.BriefError(_lib.lib().brief_last_error().decode())
-        if self._ws is None or self._ws.numel() * 4 < need:
-            self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev)
+        self.ensure_train_buffers(n)
         dims, lo, hi = grid
         g = self._grid(dims, lo, hi)
         pop, seed, step = rng if (rng is not None and idx is None) else (0, 0, 0)      # rng = (pop, seed, step): in-kernel sampling
@@ -308,6 +300,19 @@ class SIREN:
             float(lr), betas[0], betas[1], eps, int(t), _lib.ptr(self.grads), _lib.ptr(self._loss),
             _lib.ptr(self._ws), self._ws.numel() * 4, _lib.stream_ptr()))
         return self._loss
+
+    def ensure_train_buffers(self, n):
+        """gradient / loss / workspace buffers for batches of n samples (allocated once, reused)."""
+        self._require_gpu()
+        dev = self.params.device
+        if self.grads is None:
+            self.grads = torch.zeros_like(self.params)
+            self._loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        need = _lib.lib().brief_train_workspace_bytes(C.byref(self.desc), int(n))
+        if need < 0:
+            raise _lib.BriefError(_lib.lib().brief_last_error().decode())
+        if self._ws is None or self._ws.numel() * 4 < need:
+            self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev)
 
     # ---- budget -> width (utils/Networks.py:291-314)
     @staticmethod

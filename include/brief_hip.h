@@ -106,6 +106,47 @@ int brief_siren_fit_step(const brief_siren_desc *d, float *params, float *packed
                          int optim_kind, float *state1, float *state2, double lr, double beta1, double beta2, double eps, int64_t t,
                          float *grads, float *loss_out, void *workspace, int64_t workspace_bytes, void *stream);
 
+/* ---- many steps per call -------------------------------------------------------------------------
+ * One independent fit (one block of a DivideTask partition, or the whole volume of a SingleTask): everything
+ * the loop `for steps in range(1, max_steps + 1)` of main.py:385-402 touches, as plain device pointers.
+ * `batch` is the per-step template: with idx == NULL and rng_pop > 0 the voxel indices of step t are drawn
+ * in-kernel with rng_step = t (RandompointSampler, main.py:154-163); with rng_pop == 0 every step sees the
+ * same batch (RandomCubeSampler at its default: the whole volume, main.py:112-125).  A per-step idx stream
+ * cannot be expressed here: use brief_siren_fit_step for replayed indices.
+ * lr schedule = torch MultiStepLR stepped after every optimizer step (utils/misc.py:184-197, main.py:400):
+ * `lr` is the value in force for step t0 + 1; whenever the number of finished steps equals a milestone the
+ * running value is multiplied by gamma (once per occurrence).  n_milestones == 0: constant lr. */
+typedef struct brief_fit_job {
+    brief_siren_desc desc;
+    brief_grid_desc grid;
+    brief_batch_desc batch;
+    float *params, *packed;        /* canonical parameters and their fragment-ordered copy (repacked on entry) */
+    float *state1, *state2;        /* optimizer state (exp_avg | exp_inf or exp_avg_sq); unused for SGD */
+    float *grads;                  /* [param_count]: gradient of the last step */
+    float *loss_out;               /* device scalar: loss of the last step */
+    float *loss_log;               /* device [steps] or NULL: loss of every step of this call */
+    void *workspace;               /* brief_train_workspace_bytes(desc, batch.n); private to this job */
+    int64_t workspace_bytes;
+    int32_t loss_kind, optim_kind;
+    float thr, beta;
+    double lr, beta1, beta2, eps;
+    const int64_t *milestones;     /* host array, ascending */
+    int32_t n_milestones, reserved;
+    double gamma;
+    int64_t t0;                    /* optimizer steps already taken; this call runs steps t0+1 .. t0+steps */
+} brief_fit_job;
+
+/* `steps` iterations of brief_siren_fit_step enqueued back to back on `stream` (3 launches each, no host
+ * synchronisation, nothing allocated).  Bit-identical to calling brief_siren_fit_step `steps` times. */
+int brief_siren_fit(const brief_fit_job *job, int64_t steps, void *stream);
+
+/* Grouped independent fits (the per-block loop of main.py:547-575 for the blocks one GPU owns): job j runs on
+ * an internal HIP stream j mod 8, forked from and joined back into `stream` with events, so that kernels of
+ * different blocks overlap (narrow nets leave most of the 256 CUs idle between their launches).  Each job's
+ * results are bit-identical to brief_siren_fit on its own; jobs must not share any buffer except read-only
+ * targets/weights.  Call from one host thread per process (one process per GPU). */
+int brief_multi_fit(const brief_fit_job *jobs, int32_t njobs, int64_t steps, void *stream);
+
 /* optimizer.step() of main.py:399 (torch.optim.Adamax/Adam/SGD single-tensor rules); t is the
  * 1-based step count, lr the scheduler's current value.  state1/state2: exp_avg / exp_inf|exp_avg_sq. */
 int brief_optim_step(int kind, float *params, const float *grads, float *state1, float *state2, int64_t count,

@@ -92,6 +92,37 @@ def test_dividetask_single_rank(tmp_path):
     assert abs(-10 * np.log10((d * d).mean() / 65535.0 ** 2) - res[200]["psnr"]) < 1e-6
 
 
+def test_dividetask_cotrained_blocks_equal_serial_blocks(tmp_path, monkeypatch):
+    """the blocks a rank owns are trained together (brief_multi_fit, one HIP stream per block); every weight
+    file must be byte-identical to the block-after-block run (BRIEF_COTRAIN=0)."""
+    from brief_pytorch_amd.synthetic import make_volume
+    vol = make_volume((16, 48, 32), seed=5)
+    path = str(tmp_path / "blk.tif")
+    save_img(path, vol)
+    runs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("BRIEF_COTRAIN", mode)
+        opt = _opt(tmp_path / ("m" + mode), 150, "50,100", 30000.0)
+        cf = opt.CompressFramework
+        cf.Compress.divide.divide_type = "total_1_3_2"
+        cf.Compress.divide.param_alloc = "by_size"
+        Log = MyLogger(**opt.Log)
+        torch.manual_seed(42)
+        fw = NFGR(cf, Log=Log)
+        res = fw.compress_divide(path, opt)
+        assert sorted(res) == [50, 100, 150]
+        files = {}
+        for k in (50, 100, 150):
+            mdir = os.path.join(Log.logdir, "steps%d" % k, "compressed", "module")
+            for blk in sorted(os.listdir(mdir)):
+                for f in sorted(os.listdir(os.path.join(mdir, blk, "module"))):
+                    files[(k, blk, f)] = open(os.path.join(mdir, blk, "module", f), "rb").read()
+        runs[mode] = (files, {k: res[k]["psnr"] for k in res})
+        Log.close()
+    assert len(runs["1"][0]) == 3 * 6 * 10 and runs["1"][0] == runs["0"][0]
+    assert runs["1"][1] == runs["0"][1]
+
+
 def test_dividetask_vessel_shaped(tmp_path):
     """BASELINE config 5 in small: opt/DivideTask/vessel.yaml (adaptotal, <= 4 blocks sized by cal_divide_num,
     by_size budget, 7-layer nets, w0 = 10) on a 16x128x128 vessel-like stack, 400 steps."""

@@ -338,6 +338,64 @@ def test_fit_step_equals_separate_calls(L, F, name):
         assert torch.equal(ma.packed, mb.packed)
 
 
+def _mk_fitter(L, F, dims, sampler, n, seed, sched=None, opt="Adamax"):
+    from brief_pytorch_amd.fit import Fitter
+    torch.manual_seed(seed)
+    m = SIREN(coords_channel=3, data_channel=1, features=F, layers=L, w0=20.0).to(DEV)
+    pop = int(np.prod(dims))
+    tv = (torch.rand(pop, 1, generator=torch.Generator().manual_seed(seed + 1)) * 100).to(DEV)
+    return Fitter(m, tv, dims, sampler=sampler, sample_size=n, seed=seed, scheduler=sched, optimizer=opt)
+
+
+@pytest.mark.parametrize("L,F,sampler,opt", [(5, 22, "full", "Adamax"), (4, 96, "randompoint", "Adam"), (3, 64, "randompoint", "SGD")])
+def test_fit_many_steps_per_call_equals_single_steps(L, F, sampler, opt):
+    """brief_siren_fit(steps) == steps x brief_siren_fit_step, bit for bit, including the MultiStepLR
+    bookkeeping (a doubled milestone multiplies twice) and a call that starts in the middle of the schedule."""
+    sched = {"name": "MultiStepLR", "milestones": [7, 15, 15, 30], "gamma": 0.5}
+    dims = (16, 24, 20)
+    a = _mk_fitter(L, F, dims, sampler, 3000, 11, sched, opt)
+    b = _mk_fitter(L, F, dims, sampler, 3000, 11, sched, opt)
+    assert torch.equal(a.m.params, b.m.params)
+    ref = [float(a.step()) for _ in range(40)]
+    log1 = b.run(12, log=True)
+    log2 = b.run(28, log=True)
+    got = torch.cat([log1, log2]).cpu().numpy()
+    assert b.t == 40 and torch.equal(a.m.params, b.m.params) and torch.equal(a.s1, b.s1) and torch.equal(a.s2, b.s2)
+    assert np.array_equal(np.asarray(ref, np.float32), got)
+    assert float(b.m._loss) == ref[-1]
+    assert torch.equal(a.m.packed, b.m.packed)
+
+
+def test_multi_fit_equals_individual_fits():
+    """brief_multi_fit: blocks co-trained on internal streams give exactly the results of fitting each alone
+    (10 jobs > 8 pool streams: two jobs share a stream)."""
+    from brief_pytorch_amd.fit import MultiFitter
+    shapes = [(5, 22, (16, 16, 16), "full", 0), (7, 56, (8, 32, 32), "randompoint", 2500), (3, 64, (16, 16, 16), "full", 0),
+              (5, 256, (8, 32, 32), "randompoint", 3000), (4, 35, (8, 16, 16), "full", 0), (9, 30, (8, 16, 16), "randompoint", 1000),
+              (2, 16, (8, 8, 8), "full", 0), (5, 130, (8, 16, 32), "randompoint", 2000), (6, 40, (8, 16, 16), "full", 0),
+              (3, 300, (8, 16, 16), "randompoint", 1500)]
+    solo = [_mk_fitter(L, F, d, s, n, 100 + i) for i, (L, F, d, s, n) in enumerate(shapes)]
+    group = [_mk_fitter(L, F, d, s, n, 100 + i) for i, (L, F, d, s, n) in enumerate(shapes)]
+    for f in solo:
+        f.run(30)
+    mf = MultiFitter(group)
+    logs = mf.run(18, log=True)
+    mf.run(12)
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(solo, group)):
+        assert b.t == 30 and torch.equal(a.m.params, b.m.params), shapes[i]
+        assert float(a.m._loss) == float(b.m._loss)
+        assert logs[i].shape == (18,) and torch.isfinite(logs[i]).all()
+
+
+def test_fit_job_rejects_replayed_indices():
+    from brief_pytorch_amd._lib import BriefError
+    f = _mk_fitter(3, 16, (8, 8, 8), "randompoint", 100, 1)
+    f.index_stream = lambda t: torch.zeros(100, dtype=torch.int64, device=DEV)
+    with pytest.raises(BriefError):
+        f.run(2)
+
+
 def test_in_kernel_sampling_equals_index_kernel():
     """the Philox stream drawn inside the fused kernel is the one brief_sample_indices writes"""
     dims = (24, 40, 56)
