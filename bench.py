@@ -34,7 +34,8 @@ from brief_pytorch_amd.networks import SIREN  # noqa: E402
 from brief_pytorch_amd.synthetic import make_volume_torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz x 256 FLOP/clk
-LAYERS, FEATURES, W0, SAMPLE = 5, 256, 20.0, 100000
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # same guide: dense bf16 (v_mfma_f32_32x32x16_bf16); only used by --precision bf16
+LAYERS, FEATURES, W0, SAMPLE = 5, 256, 20.0, 100000      # BASELINE config 2 (the metric's shape); --config c3 = 8x512
 BLOCK = (512, 512, 512)
 
 
@@ -77,6 +78,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-psnr", action="store_true")
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
+                    help="fp32 = the metric (exact f32 MFMA); bf16 = BASELINE config 3's arithmetic (extra lines, never the default)")
+    ap.add_argument("--config", choices=["c2", "c3"], default="c2", help="c2: 4x256 SIREN (the metric); c3: 8x512 SIREN")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -98,6 +102,9 @@ def main():
     dev = torch.device("cuda", torch.cuda.current_device())
     red_dev = dev if backend == "nccl" else torch.device("cpu")
     _lib.lib()   # fails loudly when the HIP extension is missing
+    global LAYERS, FEATURES
+    if args.config == "c3":
+        LAYERS, FEATURES = 9, 512
 
     # ---- data: this rank's block, generated and normalised on the device (utils/io.py:65-80 op order)
     vol = make_volume_torch(BLOCK, seed=42 + rank, device=dev)
@@ -107,7 +114,7 @@ def main():
     tgt *= np.float32(100.0)
     tgt += np.float32(0.0)
     torch.manual_seed(42)
-    net = SIREN(coords_channel=3, data_channel=1, features=FEATURES, layers=LAYERS, w0=W0).to(dev)
+    net = SIREN(coords_channel=3, data_channel=1, features=FEATURES, layers=LAYERS, w0=W0, precision=args.precision).to(dev)
     fit = Fitter(net, tgt, BLOCK, sampler="randompoint", sample_size=SAMPLE, optimizer="Adamax", lr=1e-3,
                  scheduler={"name": "MultiStepLR", "milestones": [50000, 60000, 70000], "gamma": 0.2}, seed=42 + rank)
 
@@ -155,6 +162,9 @@ def main():
         except Exception:
             pass
         train_f, fused_f, _ = flops_per_sample(LAYERS, FEATURES)
+        peak = PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
+        if args.precision != "fp32" or args.config != "c2":
+            traffic = None                  # the committed counter passes are for the default configuration only
         fused_ms = tot_ms.value / max(launches.value, 1)
         achieved = fused_f * SAMPLE / (fused_ms * 1e-3) / 1e12
         ms_step = elapsed * 1e3 / args.steps
@@ -162,17 +172,19 @@ def main():
         out = {
             "metric": "encode_voxels_per_sec", "value": value, "unit": "voxels/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "SingleTask 512^3 synthetic uint16 volume%s, SIREN 4x256 (layers=5, features=256, w0=20), "
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
+            "config": {"workload": "SingleTask 512^3 synthetic uint16 volume%s, SIREN %dx%d (layers=%d, features=%d, w0=20), "
                                    "randompoint sample_size=100000, datal2, Adamax lr=1e-3" %
-                                   ("" if world == 1 else " per rank (DivideTask: %d independent 512^3 blocks)" % world),
+                                   ("" if world == 1 else " per rank (DivideTask: %d independent 512^3 blocks)" % world,
+                                    LAYERS - 1, FEATURES, LAYERS, FEATURES),
                        "volume": list(BLOCK), "layers": LAYERS, "features": FEATURES, "sample_size": SAMPLE,
                        "params": net.param_count, "bits_per_voxel": 32.0 * net.param_count / float(np.prod(BLOCK))},
-            "roofline": {"bound": "mfma", "kernel": "k_fused<8,true> (forward+loss+dgrad)", "achieved": achieved,
-                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": ("k_fused<%d,true>" if args.precision == "fp32" else "k16<%d,true,1>") % (FEATURES // 32)
+                         + " (forward+loss+dgrad)", "achieved": achieved,
+                         "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": traffic, "kernel_ms": fused_ms, "flop_per_launch": fused_f * SAMPLE,
                          "step_tflops": train_f * SAMPLE / (ms_step * 1e-3) / 1e12,
-                         "step_frac": train_f * SAMPLE / (ms_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS},
+                         "step_frac": train_f * SAMPLE / (ms_step * 1e-3) / 1e12 / peak},
             "loss": float(loss.item()), "psnr_db": psnr, "psnr_after_steps": args.steps + args.warmup,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BRIEF_LIB", os.path.join(_HERE, "libbrief_hip.so"))   # BRIEF_LIB: A/B diagnostics only
 SRC = os.path.join(_HERE, "csrc", "brief_hip.hip")
-_DEPS = [SRC, os.path.join(_HERE, "csrc", "brief_layout.h"), os.path.join(_HERE, "csrc", "brief_math.h"),
+_DEPS = [SRC, os.path.join(_HERE, "csrc", "brief_layout.h"), os.path.join(_HERE, "csrc", "brief_math.h"), os.path.join(_HERE, "csrc", "brief_bf16.inc"),
          os.path.join(os.path.dirname(_HERE), "include", "brief_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
@@ -21,7 +21,7 @@ class BriefError(RuntimeError):
 
 class SirenDesc(C.Structure):
     _fields_ = [("cin", C.c_int32), ("cout", C.c_int32), ("layers", C.c_int32), ("features", C.c_int32),
-                ("w0_first", C.c_float), ("w0_hidden", C.c_float), ("output_act", C.c_int32), ("reserved", C.c_int32)]
+                ("w0_first", C.c_float), ("w0_hidden", C.c_float), ("output_act", C.c_int32), ("precision", C.c_int32)]
 
 
 class GridDesc(C.Structure):
@@ -47,6 +47,7 @@ class FitJob(C.Structure):          # brief_fit_job
 LOSS_KIND = {"datal2": 0, "datasmoothl1": 1}
 OPT_KIND = {"Adamax": 0, "Adam": 1, "SGD": 2}
 OUT_F32, OUT_U8, OUT_U16 = 0, 1, 2
+PRECISION = {"fp32": 0, "f32": 0, "bf16": 1}
 
 EXPORTS = ["brief_version", "brief_last_error", "brief_param_count", "brief_packed_count",
            "brief_train_workspace_bytes", "brief_siren_repack", "brief_siren_forward", "brief_siren_train_step", "brief_siren_fit_step",

@@ -85,6 +85,7 @@ struct FusedArgs {
     float *D;            // [(L-2)][FP][npad]   deltas of layers 1..L-2
     int64_t npad;
     float *rec;          // [gridDim.x*4][BRIEF_REC_FLOATS]
+    void *S16[5];        // bf16 path: stashes H | C | D ([(L-1)][FP][npad] bf16 each), X [4][npad], G [4][npad]
     float *slabs;        // k_small only: [(L-2)][gridDim.x][FP*FP + FP] per-workgroup hidden-layer gradient partials
     float *yhat_out;     // [n][cout] or NULL
     void *out;           // forward output
@@ -695,7 +696,9 @@ __device__ __forceinline__ void small_inputs(const FusedArgs &a, int cin, int co
     float yv[4] = {0.f, 0.f, 0.f, 0.f}, wv4[4] = {1.f, 1.f, 1.f, 1.f};
     if (n < a.n) {
         const int64_t j = a.idx ? a.idx[n] : (a.rng_pop ? philox_index(n, a.rng_pop, a.rng_seed, a.rng_step) : n + a.offset);
-        if (cout == 1) {
+        if (!a.targets) {
+            // forward-only launch: no targets
+        } else if (cout == 1) {
             yv[0] = a.targets[j];
             if (a.weights) wv4[0] = a.weights[j];
         } else {
@@ -1080,6 +1083,7 @@ __global__ __launch_bounds__(256, small_wpe(HB)) void k_small(const FusedArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
+// (the bf16 kernels are included after the optimizer helpers below)
 // weight-gradient GEMM: dW_l[fo][fi] = sum_n D_l[fo][n] * sin(w Z_{l-1}[fi][n]),  db_l = sum_n D_l
 struct WgradArgs {
     brief_siren_desc d;
@@ -1422,6 +1426,11 @@ __global__ __launch_bounds__(256) void k_reduce(const ReduceArgs a, int nb_hidde
                 const int o = (int)(r / F), i = (int)(r % F);
                 blk[frag_index(NT, o, i)] = pv;                               // A-fragments of W
                 blk[(int64_t)FP * FP + frag_index(NT, i, o)] = pv;            // A-fragments of W^T
+                if (d.precision == BRIEF_PREC_BF16) {
+                    __bf16 *b16 = reinterpret_cast<__bf16 *>(a.pk + brief_pk16_off(d, l));
+                    b16[brief_frag16_index(NT, o, i)] = (__bf16)pv;
+                    b16[(int64_t)FP * FP + brief_frag16_index(NT, i, o)] = (__bf16)pv;
+                }
             } else {
                 blk[2 * (int64_t)FP * FP + (r - (int64_t)F * F)] = pv;        // bias
             }
@@ -1479,6 +1488,8 @@ __global__ __launch_bounds__(256) void k_reduce(const ReduceArgs a, int nb_hidde
     }
 }
 
+#include "brief_bf16.inc"
+
 // ---------------------------------------------------------------------------------------------
 __global__ void k_repack(const brief_siren_desc d, const float *__restrict__ params, float *__restrict__ pk)
 {
@@ -1489,6 +1500,32 @@ __global__ void k_repack(const brief_siren_desc d, const float *__restrict__ par
     if (e >= total) return;
     float v = 0.f;
     const int64_t head = brief_pk_head(d);
+    if (e >= brief_pk_count32(d)) {
+        // bf16 fragment region (two elements per float slot); the alignment gap in front of it stays zero
+        const int64_t base16 = brief_pk16_off(d, 1);
+        uint32_t word = 0;
+        if (e >= base16) {
+            const int64_t rr = e - base16;
+            const int l = 1 + (int)(rr / ((int64_t)FP * FP));
+            const float *W = params + brief_canon_hidden_off(d, l);
+            for (int half = 0; half < 2; ++half) {
+                int64_t q = (rr % ((int64_t)FP * FP)) * 2 + half;
+                const bool bwd = q >= (int64_t)FP * FP;
+                if (bwd) q -= (int64_t)FP * FP;
+                const int j = (int)(q & 7), lanei = (int)((q >> 3) & 63), sstep = (int)((q >> 9) & 1);
+                const int kt = (int)((q >> 10) % NT), mt = (int)((q >> 10) / NT);
+                const int row = 32 * mt + (lanei & 31);
+                const int col = 32 * kt + 16 * sstep + 8 * (j >> 2) + 4 * (lanei >> 5) + (j & 3);
+                float w = 0.f;
+                if (row < F && col < F) w = bwd ? W[(int64_t)col * F + row] : W[(int64_t)row * F + col];
+                union { __bf16 h; uint16_t u; } cv;
+                cv.h = (__bf16)w;
+                word |= (uint32_t)cv.u << (16 * half);
+            }
+        }
+        reinterpret_cast<uint32_t *>(pk)[e] = word;
+        return;
+    }
     if (e < (int64_t)FP * 4) {
         const int f = (int)(e >> 2), c = (int)(e & 3);
         if (f < F) {
@@ -1682,6 +1719,7 @@ static int check_desc(const brief_siren_desc *d)
     if (d->layers < 2) return fail(BRIEF_ERR_INVALID, "layers must be >= 2");
     if (d->features < 1 || d->features > 32 * BRIEF_MAX_NT)
         return fail(BRIEF_ERR_INVALID, "features must be 1..512 on the fused fp32 path");
+    if (d->precision != BRIEF_PREC_F32 && d->precision != BRIEF_PREC_BF16) return fail(BRIEF_ERR_INVALID, "precision must be BRIEF_PREC_F32 or BRIEF_PREC_BF16");
     return 0;
 }
 
@@ -1751,9 +1789,55 @@ static int small_grid(const brief_siren_desc &d, int64_t n)
     return (int)(tiles < cap ? (tiles > 0 ? tiles : 1) : cap);
 }
 
+// ---- bf16 path geometry: 128-sample workgroup tiles, one workgroup per CU; stashes in bf16 (2 per float slot)
+static int64_t npad16(int64_t n) { return (n + 127) / 128 * 128; }
+static int grid16(int64_t n)
+{
+    const int64_t tiles = (n + 127) / 128;
+    return (int)(tiles < kCUs ? (tiles > 0 ? tiles : 1) : kCUs);
+}
+static int wgrad16_splits(const brief_siren_desc &d, int64_t n)
+{
+    const int nb = brief_nt(d) / 4;                                   // 128 x 128 output blocks per side
+    const int hidden = d.layers - 2 > 0 ? d.layers - 2 : 0;
+    const int per = hidden * nb * nb + 2 * nb;
+    int64_t s = (2 * kCUs + per - 1) / per;
+    if (s < 1) s = 1;
+    if (s > 16) s = 16;
+    const int64_t nblk = npad16(n) / 64;          // k_wgrad16 splits K in 64-sample blocks; every split needs one
+    if (s > nblk) s = nblk;
+    return (int)s;
+}
+static int wgrad16_skinny_splits(const brief_siren_desc &d, int64_t n)
+{
+    // the two skinny jobs (first layer, head) stream a whole stash plane each through only 2 * nb row blocks
+    const int nb = brief_nt(d) / 4;
+    int64_t s = (2 * kCUs) / (2 * nb);
+    const int64_t nblk = npad16(n) / 64;
+    if (s > nblk) s = nblk;
+    return (int)(s < 1 ? 1 : s);
+}
+struct Ws16 { int64_t h, c, dd, x, g, rec, slabs, total; };      // offsets in floats
+static Ws16 ws16_layout(const brief_siren_desc &d, int64_t n)
+{
+    const int64_t FP = 32 * brief_nt(d), np = npad16(n), planes = d.layers - 1, hidden = d.layers - 2 > 0 ? d.layers - 2 : 0;
+    const int64_t stash = planes * FP * np / 2;                       // bf16 elements -> float slots (np is a multiple of 128)
+    Ws16 w;
+    w.h = 0; w.c = w.h + stash; w.dd = w.c + stash;
+    w.x = w.dd + stash; w.g = w.x + 4 * np / 2;
+    w.rec = w.g + 4 * np / 2;
+    w.slabs = w.rec + (int64_t)kCUs * 8 + (int64_t)kCUs * 8 * 10 /* diagnostic stamps */;
+    w.total = w.slabs + hidden * (FP * FP + FP) * (int64_t)wgrad16_splits(d, n) + 2 * FP * 4 * (int64_t)wgrad16_skinny_splits(d, n);
+    return w;
+}
+
 struct WsLayout { int64_t z, dd, rec, slabs, total; };
 static WsLayout ws_layout(const brief_siren_desc &d, int64_t n)
 {
+    if (d.precision == BRIEF_PREC_BF16) {
+        WsLayout w; w.z = w.dd = w.rec = w.slabs = 0; w.total = ws16_layout(d, n).total;
+        return w;
+    }
     const int nt = brief_nt(d);
     const int64_t FP = 32 * nt, npad = brief_npad(nt, n), hidden = d.layers - 2 > 0 ? d.layers - 2 : 0;
     const bool small = use_small(d);
@@ -1827,6 +1911,27 @@ static int launch_fused(const FusedArgs &fa, int grid, hipStream_t st)
     return 0;
 }
 
+template <bool TRAIN>
+static int launch_k16(const FusedArgs &fa, int grid, hipStream_t st)
+{
+    const int nt = brief_nt(fa.d);
+    static bool attr_done[2][2][2] = {{{false, false}, {false, false}}, {{false, false}, {false, false}}};
+#define BRIEF_CASE(NTV, COV)                                                                             \
+    if (nt == NTV && (fa.d.cout == 1) == (COV == 1)) {                                                   \
+        const size_t lds = sizeof(float) * Cfg16<NTV>::TOTAL;                                            \
+        if (!attr_done[NTV == 16][TRAIN][COV == 1]) {                                                    \
+            HIP_TRY(hipFuncSetAttribute((const void *)k16<NTV, TRAIN, COV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            attr_done[NTV == 16][TRAIN][COV == 1] = true;                                                \
+        }                                                                                                \
+        hipLaunchKernelGGL((k16<NTV, TRAIN, COV>), dim3(grid), dim3(512), lds, st, fa);                  \
+    }
+    if (nt != 8 && nt != 16) return fail(BRIEF_ERR_INVALID, "unsupported width");
+    BRIEF_CASE(8, 1) BRIEF_CASE(8, 4) BRIEF_CASE(16, 1) BRIEF_CASE(16, 4)
+#undef BRIEF_CASE
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 static int check_batch(const brief_siren_desc *d, const brief_grid_desc *grid, const brief_batch_desc *b, bool train)
 {
     if (!b || b->n < 1) return fail(BRIEF_ERR_INVALID, "empty batch");
@@ -1861,6 +1966,7 @@ int brief_siren_forward(const brief_siren_desc *d, const float *packed, const br
     fa.span = (float)(vmax - vmin);
     fa.vmin = (float)vmin;
     fa.stagger_cus = kCUs; fa.stagger = 0;
+    if (d->precision == BRIEF_PREC_BF16) return launch_k16<false>(fa, grid16(batch->n), (hipStream_t)stream);
     return launch_fused<false>(fa, fused_grid(*d, batch->n, false), (hipStream_t)stream);
 }
 
@@ -1877,13 +1983,66 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
     if (int rc = check_batch(d, grid, batch, true)) return rc;
     if (!packed || !grads || !loss_out || !workspace) return fail(BRIEF_ERR_INVALID, "null buffer");
     if (loss_kind != BRIEF_LOSS_L2 && loss_kind != BRIEF_LOSS_SMOOTHL1) return fail(BRIEF_ERR_INVALID, "bad loss_kind");
-    if ((int64_t)32 * brief_nt(*d) * brief_npad(brief_nt(*d), batch->n) * 4 >= ((int64_t)1 << 31))
+    if (d->precision == BRIEF_PREC_BF16 ? (int64_t)32 * brief_nt(*d) * npad16(batch->n) * 2 >= ((int64_t)1 << 31)
+                                       : (int64_t)32 * brief_nt(*d) * brief_npad(brief_nt(*d), batch->n) * 4 >= ((int64_t)1 << 31))
         return fail(BRIEF_ERR_INVALID, "batch too large for one train step (padded width x samples x 4 bytes must stay below 2 GiB): split it");
     const WsLayout wl = ws_layout(*d, batch->n);
     if (workspace_bytes < wl.total * (int64_t)sizeof(float)) return fail(BRIEF_ERR_WORKSPACE, "workspace too small");
     hipStream_t st = (hipStream_t)stream;
     float *ws = (float *)workspace;
     const int nt = brief_nt(*d);
+    if (d->precision == BRIEF_PREC_BF16) {
+        const Ws16 w16 = ws16_layout(*d, batch->n);
+        const int64_t np = npad16(batch->n), FP = 32 * nt;
+        const int hidden = d->layers - 2;
+        const int g16 = grid16(batch->n), nsp = wgrad16_splits(*d, batch->n);
+        const float inv16 = (float)(1.0 / ((double)batch->n * d->cout));
+        FusedArgs fa;
+        memset(&fa, 0, sizeof(fa));
+        fa.d = *d; fa.pk = packed;
+        fa.coords = batch->coords; fa.targets = batch->targets; fa.weights = batch->weights;
+        fa.idx = batch->idx; fa.offset = batch->offset; fa.n = batch->n;
+        if (!batch->idx && batch->rng_pop > 0) { fa.rng_pop = (uint64_t)batch->rng_pop; fa.rng_seed = batch->rng_seed; fa.rng_step = batch->rng_step; }
+        fill_grid(fa.grid, grid);
+        fa.loss_kind = loss_kind; fa.thr = thr; fa.beta = beta; fa.inv_count = inv16;
+        fa.npad = np; fa.rec = ws + w16.rec; fa.yhat_out = yhat_out;
+        fa.S16[0] = ws + w16.h; fa.S16[1] = ws + w16.c; fa.S16[2] = ws + w16.dd; fa.S16[3] = ws + w16.x; fa.S16[4] = ws + w16.g;
+        const bool prof16 = g_prof_on && g_prof_n < kProfSlots;
+        if (prof16) HIP_TRY(hipEventRecord(g_prof_ev[2 * g_prof_n], st));
+        if (int rc = launch_k16<true>(fa, g16, st)) return rc;
+        if (prof16) { HIP_TRY(hipEventRecord(g_prof_ev[2 * g_prof_n + 1], st)); ++g_prof_n; }
+        Wgrad16Args wa;
+        memset(&wa, 0, sizeof(wa));
+        const int nsp_s = wgrad16_skinny_splits(*d, batch->n);
+        wa.d = *d; wa.npad = np; wa.nsplit = nsp; wa.nsplit_s = nsp_s; wa.slabs = ws + w16.slabs;
+        wa.H = (const __bf16 *)(ws + w16.h); wa.D = (const __bf16 *)(ws + w16.dd);
+        wa.X = (const __bf16 *)(ws + w16.x); wa.G = (const __bf16 *)(ws + w16.g);
+        const int nb = nt / 4;
+        if (hidden > 0) hipLaunchKernelGGL(k_wgrad16<false>, dim3(hidden * nb * nb * nsp), dim3(256), sizeof(float) * 4 * W16_PANEL, st, wa);
+        hipLaunchKernelGGL(k_wgrad16<true>, dim3(2 * nb * nsp_s), dim3(256), sizeof(float) * 4 * W16_PANEL, st, wa);
+        HIP_TRY(hipGetLastError());
+        const int64_t l0c = (int64_t)d->features * d->cin + d->features;
+        const int64_t hcnt = brief_canon_head_off(*d) - l0c;
+        if (hidden > 0) {
+            ReduceArgs ra;
+            memset(&ra, 0, sizeof(ra));
+            ra.d = *d; ra.slabs = ws + w16.slabs; ra.nsplit = nsp; ra.sgroups = 1;
+            ra.grads = grads; ra.loss_out = loss_out; ra.inv_count = inv16;
+            if (upd) { ra.update = 1; ra.opt = upd->opt; ra.params = upd->params; ra.s1 = upd->s1; ra.s2 = upd->s2; ra.pk = upd->pk; }
+            const int nbh = (int)((hcnt + 255) / 256);
+            hipLaunchKernelGGL(k_reduce, dim3(nbh), dim3(256), 0, st, ra, nbh);      // hidden-layer part only
+            HIP_TRY(hipGetLastError());
+        }
+        Reduce16Args r16;
+        memset(&r16, 0, sizeof(r16));
+        r16.d = *d; r16.slabs = ws + w16.slabs + (int64_t)hidden * nsp * (FP * FP + FP); r16.nsplit = nsp_s;
+        r16.rec = fa.rec; r16.nwg = g16; r16.grads = grads; r16.loss_out = loss_out; r16.inv_count = inv16;
+        if (upd) { r16.update = 1; r16.opt = upd->opt; r16.params = upd->params; r16.s1 = upd->s1; r16.s2 = upd->s2; r16.pk = upd->pk; }
+        const int64_t items = l0c + (int64_t)d->cout * d->features + d->cout + 1;
+        hipLaunchKernelGGL(k_reduce16, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, r16);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     if (const char *e = getenv("BRIEF_WG_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 4) g_wg_per_cu = v; }
     if (const char *e = getenv("BRIEF_STAGGER")) g_stagger = atoi(e);
     const bool small = use_small(*d);

@@ -47,6 +47,7 @@ BL_HD int64_t brief_canon_count(const brief_siren_desc &d)
 BL_HD int brief_nt(const brief_siren_desc &d)
 {
     const int nt = (d.features + 31) / 32;
+    if (d.precision == BRIEF_PREC_BF16) return nt <= 8 ? 8 : 16;     // the bf16 kernels exist for 256 and 512 padded features
     return nt <= 8 ? nt : (nt <= 12 ? 12 : 16);
 }
 BL_HD int64_t brief_pk_w0(const brief_siren_desc &) { return 0; }
@@ -65,10 +66,34 @@ BL_HD int64_t brief_pk_head(const brief_siren_desc &d)
     const int64_t FP = 32 * brief_nt(d);
     return FP * 4 + (int64_t)(d.layers - 2) * brief_pk_hidden_stride(d);
 }
-BL_HD int64_t brief_pk_count(const brief_siren_desc &d)
+BL_HD int64_t brief_pk_count32(const brief_siren_desc &d)
 {
     const int64_t FP = 32 * brief_nt(d);
     return brief_pk_head(d) + 4 * FP + 4;
+}
+// bf16 mode appends, per hidden layer, the bf16 A-fragments of W and of W^T for v_mfma_f32_32x32x16_bf16:
+//   Wf16 [NT(mt)][NT(kt)][2(s)][64(lane)][8(j)]:  W[32mt + i][32kt + krow(s, hi, j)]       (lane = 32 hi + i)
+//   Wb16 [NT(mt)][NT(kt)][2(s)][64(lane)][8(j)]:  W[32kt + krow(s, hi, j)][32mt + i]
+//   krow(s, hi, j) = 16 s + 8 (j >> 2) + 4 hi + (j & 3): the row an accumulator register 8s + j of lane half hi
+//   holds, so that a converted accumulator tile IS the B operand of the next layer (cdna_hip_programming.md,
+//   'An accumulator tile as the next MFMA's operand').  Offsets below are in FLOAT units (2 bf16 each).
+BL_HD int64_t brief_pk16_off(const brief_siren_desc &d, int l /*1..L-2*/)
+{
+    const int64_t FP = 32 * brief_nt(d);
+    return ((brief_pk_count32(d) + 3) / 4) * 4 + (int64_t)(l - 1) * FP * FP;
+}
+BL_HD int64_t brief_pk_count(const brief_siren_desc &d)
+{
+    if (d.precision != BRIEF_PREC_BF16) return brief_pk_count32(d);
+    return brief_pk16_off(d, d.layers - 1 > 1 ? d.layers - 1 : 1);
+}
+// index (in bf16 elements, inside one layer's Wf16 or Wb16 block) of the fragment element that multiplies
+// activation row `col` into output row `row`
+BL_HD int64_t brief_frag16_index(int NT, int row, int col)
+{
+    const int mt = row >> 5, i = row & 31, kt = col >> 5, rem = col & 31;
+    const int s = rem >> 4, r16 = rem & 15, hi = (r16 >> 2) & 1, j = ((r16 >> 3) << 2) | (r16 & 3);
+    return ((((int64_t)mt * NT + kt) * 2 + s) * 64 + 32 * hi + i) * 8 + j;
 }
 
 // --- fused-kernel geometry per NT (how the 4 waves of a workgroup split features x sample tiles)

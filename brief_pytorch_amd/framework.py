@@ -72,7 +72,10 @@ class NFGR:
         self.args = args
         self.half = opt.Compress.half
         if self.half:
-            raise NotImplementedError("Compress.half (fp16) is not available on the fused fp32 path")
+            raise NotImplementedError("Compress.half (fp16 autocast) is not available on the fused path; "
+                                      "Compress.precision: bf16 is its MI355X counterpart (bf16 MFMA, fp32 master weights)")
+        # optional key of this build (a reference YAML does not have it): fp32 (default, the parity path) | bf16
+        self.precision = str(opt.Compress.get("precision", "fp32"))
         if opt.Compress.loss.name not in ("datal2", "datasmoothl1"):
             raise NotImplementedError(opt.Compress.loss.name)
         if not opt.Compress.gpu or not torch.cuda.is_available():
@@ -87,7 +90,7 @@ class NFGR:
         return p.given_size if p.given_size > 0 else os.path.getsize(data_path) / p.filesize_ratio
 
     def init_module(self):
-        self.module["phi"] = init_phi(self.opt.Module.phi)
+        self.module["phi"] = init_phi({**dict(self.opt.Module.phi), "precision": self.precision})
 
     @staticmethod
     def estimate_module_size(ideal_module_size, opt):
@@ -124,7 +127,8 @@ class NFGR:
         cf = copy.deepcopy(opt.CompressFramework)
         cf.Module.phi.features = sideinfos["phi_features"]
         cf.Module.phi.name = sideinfos["phi_name"]
-        phi = init_phi(cf.Module.phi)
+        # decode in the arithmetic the net was fitted in (side info records it when it is not fp32)
+        phi = init_phi({**dict(cf.Module.phi), "precision": str(sideinfos.get("phi_precision", cf.Compress.get("precision", "fp32")))})
         load_model(phi, module_path, "cpu")
         phi.to(device)
         shape = list(sideinfos["data_shape"])
@@ -165,6 +169,8 @@ class NFGR:
         if C_.param.init_net_path != "none":
             load_model(phi, C_.param.init_net_path, "cpu")
         sideinfos = {**sideinfos, "data_shape": list(norm.shape), "phi_features": feats, "phi_name": opt.Module.phi.name}
+        if self.precision != "fp32":
+            sideinfos["phi_precision"] = self.precision      # extra key only off the reference's fp32 path
         dims = list(norm.shape[:-1])
         cout = norm.shape[-1]
         tgt = norm.reshape(-1, cout).to(self.device)

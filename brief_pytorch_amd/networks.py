@@ -89,15 +89,18 @@ class SIREN:
     """reference: utils/Networks.py:236-314."""
 
     def __init__(self, coords_channel=3, data_channel=1, features=256, layers=5, w0=30, res=False,
-                 output_act=False, device=None, **kwargs):
+                 output_act=False, device=None, precision="fp32", **kwargs):
+        """precision: 'fp32' (exact f32 MFMA, the parity path) or 'bf16' (hidden GEMMs on the bf16 matrix pipe,
+        f32 master weights: the MI355X counterpart of Compress.half; include/brief_hip.h: BRIEF_PREC_BF16)."""
         if res:
             # HalfResidual blocks cannot be saved by the reference's own ModelSave (SURVEY a1)
             raise NotImplementedError("SIREN(res=True) is unsupported on the fused path")
         self.coords_channel, self.data_channel = int(coords_channel), int(data_channel)
         self.features, self.layers = int(features), int(layers)
         self.w0, self.output_act = float(w0), bool(output_act)
+        self.precision = str(precision)
         self.desc = _lib.SirenDesc(self.coords_channel, self.data_channel, self.layers, self.features,
-                                   self.w0, 30.0, int(self.output_act), 0)
+                                   self.w0, 30.0, int(self.output_act), _lib.PRECISION[self.precision])
         F = self.features
         self._shapes = [(F, self.coords_channel)] + [(F, F)] * (self.layers - 2) + [(self.data_channel, F)]
         self.param_count = sum(o * i + o for o, i in self._shapes)

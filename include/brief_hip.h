@@ -35,8 +35,12 @@ typedef struct {
     float w0_first;
     float w0_hidden;
     int32_t output_act;
-    int32_t reserved;
+    int32_t precision;   /* BRIEF_PREC_F32 (0): exact f32 MFMA everywhere.  BRIEF_PREC_BF16 (1): the hidden F x F GEMMs run on the
+                          * bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, f32 accumulate, f32 master weights, f32 first layer, head,
+                          * loss, reductions and optimizer); activations/deltas are stashed as bf16.  The MI355X counterpart of the
+                          * reference's low-precision mode (Compress.half, main.py:388-399), pinned by a PSNR band, not bitwise. */
 } brief_siren_desc;
+enum { BRIEF_PREC_F32 = 0, BRIEF_PREC_BF16 = 1 };
 
 /* create_flattened_coords(shape, mode)  utils/dataset.py:36-60: linspace(lo,hi,n) per axis, (d,h,w) order */
 typedef struct {

@@ -1,0 +1,170 @@
+"""BRIEF_PREC_BF16 (BASELINE config 3: 8x512 SIREN, bf16 MFMA).  The hidden GEMMs run on the bf16 matrix pipe
+with fp32 master weights, so parity is a band, not bitwise: forward and gradients
+against the fp32 path on the SAME parameters (bf16 has 8 significant bits: a few 1e-3 relative), bit-reproducible
+run to run, and the PSNR of a short fit within 1 dB of the fp32 fit from the same init and sample stream (the
+reference vs itself moves by 0.01 dB at the END of a 20 000-step fit, Appendix F; mid-fit, where these tests stop,
+diverged trajectories differ by several 0.1 dB in either direction)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from brief_pytorch_amd import _lib, config
+from brief_pytorch_amd.fit import Fitter
+from brief_pytorch_amd.networks import SIREN
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+def pair(L, F, cin=3, cout=1, seed=0):
+    torch.manual_seed(seed)
+    m32 = SIREN(coords_channel=cin, data_channel=cout, features=F, layers=L, w0=20).to(DEV)
+    m16 = SIREN(coords_channel=cin, data_channel=cout, features=F, layers=L, w0=20, precision="bf16").to(DEV)
+    m16.params.copy_(m32.params)
+    m16._stale = True
+    return m32, m16
+
+
+@pytest.mark.parametrize("L,F,cin,cout,n", [(3, 256, 3, 1, 1000), (5, 256, 3, 1, 5000), (5, 200, 3, 1, 777), (4, 100, 2, 3, 300),
+                                             (4, 512, 3, 1, 3000), (9, 512, 3, 1, 20000), (2, 300, 3, 1, 500), (6, 384, 3, 2, 129)])
+def test_forward_and_gradients_track_fp32(L, F, cin, cout, n):
+    m32, m16 = pair(L, F, cin, cout, seed=L * 1000 + F)
+    g = torch.Generator().manual_seed(n)
+    x = (torch.rand(n, cin, generator=g) * 2 - 1).to(DEV)
+    y = (torch.rand(n, cout, generator=g) * 100).to(DEV)
+    w = torch.where(torch.rand(n, cout, generator=g) < 0.5, 0.25, 1.0).to(DEV)
+    o32, o16 = m32.forward(x), m16.forward(x)
+    assert rel(o16, o32) < 3e-2 and float((o16 - o32).abs().max()) < 5e-3       # outputs are O(0.05): bf16 noise through L-2 layers
+    l32, _ = m32.train_step(n, y, coords=x, weights=w, thr=30.0)
+    g32 = m32.grads.clone()
+    l16, y16 = m16.train_step(n, y, coords=x, weights=w, thr=30.0, want_yhat=True)
+    g16 = m16.grads.clone()
+    assert abs(float(l16) - float(l32)) / float(l32) < 1e-4
+    assert rel(y16, o16) < 1e-6                                                   # train and decode forward agree
+    assert rel(g16, g32) < 2e-2
+    # per layer: first layer (through all bf16 layers) is the loosest
+    F_, offs = F, [0, F * cin + F]
+    for _ in range(L - 2):
+        offs.append(offs[-1] + F_ * F_ + F_)
+    offs.append(offs[-1] + F_ * cout + cout)
+    for i in range(len(offs) - 1):
+        assert rel(g16[offs[i]:offs[i + 1]], g32[offs[i]:offs[i + 1]]) < 3e-2, i
+    # fixed summation order: bit-reproducible
+    l16b, _ = m16.train_step(n, y, coords=x, weights=w, thr=30.0)
+    assert torch.equal(g16, m16.grads) and float(l16) == float(l16b)
+
+
+def test_bf16_layout_and_errors():
+    L = _lib.lib()
+    import ctypes as C
+    d = _lib.SirenDesc(3, 1, 9, 512, 20.0, 30.0, 0, 1)
+    fp = 512
+    c32 = fp * 4 + 7 * (2 * fp * fp + fp) + 4 * fp + 4
+    assert L.brief_packed_count(C.byref(d)) == (c32 + 3) // 4 * 4 + 7 * fp * fp      # + bf16 W and W^T fragments, 2 per float slot
+    d2 = _lib.SirenDesc(3, 1, 5, 40, 20.0, 30.0, 0, 1)                                # narrow nets pad to 256 in bf16 mode
+    assert L.brief_packed_count(C.byref(d2)) == (256 * 4 + 3 * (2 * 256 * 256 + 256) + 4 * 256 + 4 + 3) // 4 * 4 + 3 * 256 * 256
+    bad = _lib.SirenDesc(3, 1, 5, 256, 20.0, 30.0, 0, 7)
+    assert L.brief_packed_count(C.byref(bad)) < 0 and b"precision" in L.brief_last_error()
+    with pytest.raises(KeyError):
+        SIREN(features=64, layers=3, precision="fp8")
+
+
+@pytest.mark.parametrize("opt", ["Adamax", "Adam"])
+def test_bf16_fit_step_equals_separate_calls_and_many_steps(opt):
+    """fused optimizer write-through (f32 + bf16 fragment copies) == train_step + optim_step + repack; brief_siren_fit loops it"""
+    def mk():
+        torch.manual_seed(3)
+        m = SIREN(features=256, layers=4, w0=20, precision="bf16").to(DEV)
+        tv = (torch.rand(16 * 16 * 16, 1, generator=torch.Generator().manual_seed(4)) * 100).to(DEV)
+        return m, tv, Fitter(m, tv, (16, 16, 16), sampler="randompoint", sample_size=3000, optimizer=opt, seed=9)
+    ma, tva, fa = mk()
+    mb, tvb, fb = mk()
+    mc, tvc, fc = mk()
+    for _ in range(6):
+        fa.step()
+    fb.run(6)
+    # separate calls on c
+    import ctypes as C
+    Lb = _lib.lib()
+    s1, s2 = torch.zeros_like(mc.params), torch.zeros_like(mc.params)
+    for t in range(1, 7):
+        idx = torch.empty(3000, dtype=torch.int64, device=DEV)
+        _lib.check(Lb.brief_sample_indices(_lib.ptr(idx), 3000, 16 ** 3, 9, t, _lib.stream_ptr()))
+        mc.train_step(3000, tvc, idx=idx, grid=((16, 16, 16), -1.0, 1.0))
+        _lib.check(Lb.brief_optim_step(_lib.OPT_KIND[opt], _lib.ptr(mc.params), _lib.ptr(mc.grads), _lib.ptr(s1), _lib.ptr(s2),
+                                      mc.params.numel(), 1e-3, 0.9, 0.999, 1e-8, t, _lib.stream_ptr()))
+        mc._stale = True
+    assert torch.equal(ma.params, mb.params) and torch.equal(ma.params, mc.params)
+    mc.sync_packed()
+    assert torch.equal(ma.packed, mc.packed)          # incl. the bf16 fragment region
+
+
+@pytest.mark.parametrize("L,F,steps", [(5, 256, 3000), (9, 512, 2500)])
+def test_bf16_fit_reaches_fp32_quality(L, F, steps):
+    """C2 / C3 in small: a 48^3 textured volume, bf16 vs fp32 from the same init and the same sample stream"""
+    from brief_pytorch_amd.synthetic import make_volume_torch
+    dims = (48, 48, 48)
+    vol = make_volume_torch(dims, seed=7, detail=32)
+    vf = vol.to(torch.int32).float().reshape(-1, 1)
+    vmin, vmax = float(vf.min()), float(vf.max())
+    tv = ((vf - vmin) / (vmax - vmin) * 100.0).contiguous()
+    flat = -10.0 * np.log10(float(vf.var()) / 65535.0 ** 2)        # PSNR of the best constant
+    out = {}
+    for prec in ("fp32", "bf16"):
+        torch.manual_seed(1)
+        m = SIREN(features=F, layers=L, w0=20, precision=prec).to(DEV)
+        fit = Fitter(m, tv, dims, sampler="randompoint", sample_size=30000, seed=5)
+        fit.run(steps)
+        dec = m.decode_grid(dims, out_kind="u16", scale=(0.0, 100.0), vrange=(vmin, vmax))
+        sse = torch.zeros(1, dtype=torch.float64, device=DEV)
+        _lib.check(_lib.lib().brief_sse_u16(_lib.ptr(vol), _lib.ptr(dec), vol.numel(), _lib.ptr(sse), _lib.stream_ptr()))
+        out[prec] = -10.0 * np.log10(sse.item() / vol.numel() / 65535.0 ** 2)
+    print(L, F, steps, "flat %.2f" % flat, out)
+    # mid-fit, with PSNR still climbing ~2 dB per 1000 steps, the two trajectories have drifted apart (chaotic divergence,
+    # SURVEY Appendix F): measured bf16 - fp32 = +0.74 dB at 1500 and +1.17 dB at 3000 steps of the 4x256 case.  The
+    # claim tested is one-sided: bf16 is not worse than fp32 by more than 1 dB (and not absurdly better either).
+    assert -1.0 < out["bf16"] - out["fp32"] < 3.0, (flat, out)
+    if F == 256:
+        assert out["fp32"] > flat + 8.0, (flat, out)
+
+
+def test_singletask_bf16_option(tmp_path):
+    """Compress.precision: bf16 through the framework: artefacts as fp32 weight files, side info records the precision,
+    decoding the stored artefact reproduces the stored volume"""
+    from brief_pytorch_amd.framework import NFGR, MyLogger
+    from brief_pytorch_amd.synthetic import make_volume
+    from brief_pytorch_amd.tool import read_img, save_img
+    vol = make_volume((16, 32, 32), seed=3)
+    path = str(tmp_path / "v.tif")
+    save_img(path, vol)
+    opt = config.load(os.path.join(ROOT, "opt", "SingleTask", "default.yaml"))
+    cf = opt.CompressFramework
+    cf.Compress.max_steps = 150
+    cf.Compress.checkpoints = "none"
+    cf.Compress.param.filesize_ratio = 0
+    cf.Compress.param.given_size = 4.0 * SIREN.calc_param_count(3, 1, 160, 4)
+    cf.Module.phi.layers = 4
+    cf.Compress.precision = "bf16"
+    opt.Log.outputs_dir = str(tmp_path / "outputs")
+    opt.Log.time = False
+    Log = MyLogger(**opt.Log)
+    torch.manual_seed(42)
+    fw = NFGR(cf, Log=Log)
+    res = fw.compress(path)
+    assert res[150]["psnr"] > 25
+    sdir = os.path.join(Log.logdir, "steps150")
+    side = config.load(os.path.join(sdir, "compressed", "sideinfos.yaml"))
+    assert side["phi_precision"] == "bf16" and side["phi_features"] == 160
+    assert os.path.getsize(os.path.join(sdir, "compressed", "module", "weight-1-160-160")) == 160 * 160 * 4
+    again = NFGR.decompress(config.to_opt({"CompressFramework": cf}), os.path.join(sdir, "compressed", "module"), dict(side))
+    assert np.array_equal(again, read_img(os.path.join(sdir, "decompressed", "v_decompressed.tif")))
+    cf.Compress.half = True
+    with pytest.raises(NotImplementedError):
+        NFGR(cf, Log=None)
