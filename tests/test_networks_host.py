@@ -77,3 +77,20 @@ def test_capi_exports_and_sizes():
     assert L.brief_packed_count(C.byref(_lib.SirenDesc(3, 1, 5, 300, 20.0, 30.0, 0, 0))) == 384 * 4 + 3 * (2 * 384 * 384 + 384) + 4 * 384 + 4
     bad = _lib.SirenDesc(3, 1, 5, 513, 20.0, 30.0, 0, 0)
     assert L.brief_param_count(C.byref(bad)) == -1 and b"features" in L.brief_last_error()
+
+
+def test_bf16_packed_layout_counts():
+    """BRIEF_PREC_BF16: widths pad to 256 / 512 and the packed buffer grows by the bf16 W / W^T fragment copies
+    (host-side layout arithmetic only: no GPU needed)"""
+    import ctypes as C
+    L = _lib.lib()
+    d = _lib.SirenDesc(3, 1, 9, 512, 20.0, 30.0, 0, 1)
+    fp = 512
+    c32 = fp * 4 + 7 * (2 * fp * fp + fp) + 4 * fp + 4
+    assert L.brief_packed_count(C.byref(d)) == (c32 + 3) // 4 * 4 + 7 * fp * fp
+    d2 = _lib.SirenDesc(3, 1, 5, 40, 20.0, 30.0, 0, 1)
+    assert L.brief_packed_count(C.byref(d2)) == (256 * 4 + 3 * (2 * 256 * 256 + 256) + 4 * 256 + 4 + 3) // 4 * 4 + 3 * 256 * 256
+    assert L.brief_param_count(C.byref(d2)) == 40 * 3 + 40 + 3 * (40 * 40 + 40) + 40 + 1
+    assert L.brief_train_workspace_bytes(C.byref(d), 100000) > 3 * 8 * 512 * 100096 * 2
+    bad = _lib.SirenDesc(3, 1, 5, 256, 20.0, 30.0, 0, 7)
+    assert L.brief_packed_count(C.byref(bad)) < 0 and b"precision" in L.brief_last_error()
