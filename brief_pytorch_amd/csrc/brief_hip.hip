@@ -1798,13 +1798,21 @@ static int grid16(int64_t n)
 }
 static int wgrad16_splits(const brief_siren_desc &d, int64_t n)
 {
-    const int nb = brief_nt(d) / 4;                                   // 128 x 128 output blocks per side
+    const int nt = brief_nt(d);
     const int hidden = d.layers - 2 > 0 ? d.layers - 2 : 0;
-    const int per = hidden * nb * nb + 2 * nb;
-    int64_t s = (2 * kCUs + per - 1) / per;
+    const int64_t nblk = npad16(n) / 64;          // K is split in 64-sample blocks; every split needs one
+    int64_t s;
+    if (nt == 16) {
+        // k_wgrad16_big: one 512-thread workgroup per CU; a whole number of workgroups per CU-round, not 1.1 rounds
+        const int per = hidden * 4;               // (512 / 256)^2 output blocks per layer
+        s = per > 0 ? kCUs / per : 1;
+    } else {
+        const int nb = nt / 4;                    // 128 x 128 output blocks per side
+        const int per = hidden * nb * nb + 2 * nb;
+        s = (2 * kCUs + per - 1) / per;
+    }
     if (s < 1) s = 1;
     if (s > 16) s = 16;
-    const int64_t nblk = npad16(n) / 64;          // k_wgrad16 splits K in 64-sample blocks; every split needs one
     if (s > nblk) s = nblk;
     return (int)s;
 }
@@ -2014,12 +2022,20 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
         Wgrad16Args wa;
         memset(&wa, 0, sizeof(wa));
         const int nsp_s = wgrad16_skinny_splits(*d, batch->n);
-        wa.d = *d; wa.npad = np; wa.nsplit = nsp; wa.nsplit_s = nsp_s; wa.slabs = ws + w16.slabs;
+        wa.d = *d; wa.npad = np; wa.nsplit = nsp; wa.nsplit_s = nsp_s; wa.bias_jobs = nt == 16 ? 1 : 0; wa.slabs = ws + w16.slabs;
         wa.H = (const __bf16 *)(ws + w16.h); wa.D = (const __bf16 *)(ws + w16.dd);
         wa.X = (const __bf16 *)(ws + w16.x); wa.G = (const __bf16 *)(ws + w16.g);
         const int nb = nt / 4;
-        if (hidden > 0) hipLaunchKernelGGL(k_wgrad16<false>, dim3(hidden * nb * nb * nsp), dim3(256), sizeof(float) * 4 * W16_PANEL, st, wa);
-        hipLaunchKernelGGL(k_wgrad16<true>, dim3(2 * nb * nsp_s), dim3(256), sizeof(float) * 4 * W16_PANEL, st, wa);
+        if (hidden > 0 && nt == 16) {
+            static bool big_attr = false;
+            const int lds_big = (int)(sizeof(float) * 4 * W16B_PANEL);
+            if (!big_attr) { HIP_TRY(hipFuncSetAttribute((const void *)k_wgrad16_big, hipFuncAttributeMaxDynamicSharedMemorySize, lds_big)); big_attr = true; }
+            hipLaunchKernelGGL(k_wgrad16_big, dim3(hidden * 4 * nsp), dim3(512), lds_big, st, wa);
+        } else if (hidden > 0) {
+            hipLaunchKernelGGL(k_wgrad16<false>, dim3(hidden * nb * nb * nsp), dim3(256), sizeof(float) * 4 * W16_PANEL, st, wa);
+        }
+        // hidden-layer bias gradients (B = ones), first layer, head
+        hipLaunchKernelGGL(k_wgrad16<true>, dim3((wa.bias_jobs ? hidden * nb * nsp : 0) + 2 * nb * nsp_s), dim3(256), sizeof(float) * 4 * W16_PANEL, st, wa);
         HIP_TRY(hipGetLastError());
         const int64_t l0c = (int64_t)d->features * d->cin + d->features;
         const int64_t hcnt = brief_canon_head_off(*d) - l0c;
