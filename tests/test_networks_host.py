@@ -79,6 +79,25 @@ def test_capi_exports_and_sizes():
     assert L.brief_param_count(C.byref(bad)) == -1 and b"features" in L.brief_last_error()
 
 
+def test_every_function_the_header_declares_is_exported():
+    """include/brief_hip.h is the contract: each `brief_*(` prototype must be a symbol of libbrief_hip.so and be
+    listed in the ctypes layer (no compute calls: runs without a GPU)"""
+    import os
+    import re
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libbrief_hip.so not built")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "include", "brief_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)                      # prototypes only, not prose
+    names = sorted(set(re.findall(r"\b(brief_[a-z0-9_]+)\s*\(", text)))
+    assert len(names) >= 19 and "brief_siren_fit_step" in names and "brief_multi_fit" in names
+    L = C.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(L, n), "declared in brief_hip.h but not exported: " + n
+        assert n in _lib.EXPORTS, "exported but missing from brief_pytorch_amd/_lib.py: " + n
+    assert sorted(_lib.EXPORTS) == names
+
+
 def test_bf16_packed_layout_counts():
     """BRIEF_PREC_BF16: widths pad to 256 / 512 and the packed buffer grows by the bf16 W / W^T fragment copies
     (host-side layout arithmetic only: no GPU needed)"""
