@@ -16,8 +16,8 @@ torch.cuda.synchronize()
 FP, npad, hidden = 256, 100000, 3
 rec_off = 2 * hidden * FP * npad
 nrec = 512 * 4
-rec = m._ws[rec_off:rec_off + nrec * 528].view(nrec, 528).cpu().numpy()
-st = rec[:, 518:528]
+rec = m._ws[rec_off:rec_off + nrec * 1056].view(nrec, 1056).cpu().numpy()
+st = rec[:, 1030:1040]
 names = ['inputs+layer0', 'fwd chain', 'barrier after chain', 'fwd epilogue(stash,sincos,image)', 'barrier after image', 'head+loss',
          'head-grad + delta + d0 transposes', 'D store + z prefetch', 'barriers+image before bwd chain', 'bwd chain']
 tot = st.sum(1)
@@ -26,7 +26,7 @@ for i, nme in enumerate(names):
     v = st[tot > 0, i]
     print('%-36s mean %9.0f cycles  %5.1f%%   (min %9.0f max %9.0f)' % (nme, v.mean(), 100 * v.mean() / tot[tot > 0].mean(), v.min(), v.max()))
 # ---- wgrad stamps
-rec_floats = 256 * 4 * 4 * 528
+rec_floats = 256 * 4 * 4 * 1056
 ws = m._ws[rec_off + rec_floats - 256 * 8 * 8: rec_off + rec_floats].view(256, 8, 8).cpu().numpy()
 w = ws[:255].reshape(-1, 8)[:, :4]
 tot = w.sum(1)
