@@ -85,6 +85,8 @@ struct FusedArgs {
     float *D;            // [(L-2)][FP][npad]   deltas of layers 1..L-2
     int64_t npad;
     float *rec;          // [gridDim.x*4][BRIEF_REC_FLOATS]
+    int64_t n_begin, n_end;   // bf16 path: the sample range of this launch (body / tail launches)
+    int rec_base;             // bf16 path: first record slot of this launch
     void *S16[5];        // bf16 path: stashes H | C | D ([(L-1)][FP][npad] bf16 each), X [4][npad], G [4][npad]
     float *slabs;        // k_small only: [(L-2)][gridDim.x][FP*FP + FP] per-workgroup hidden-layer gradient partials
     float *yhat_out;     // [n][cout] or NULL
@@ -1834,7 +1836,7 @@ static Ws16 ws16_layout(const brief_siren_desc &d, int64_t n)
     w.h = 0; w.c = w.h + stash; w.dd = w.c + stash;
     w.x = w.dd + stash; w.g = w.x + 4 * np / 2;
     w.rec = w.g + 4 * np / 2;
-    w.slabs = w.rec + (int64_t)kCUs * 8 + (int64_t)kCUs * 8 * 10 /* diagnostic stamps */;
+    w.slabs = w.rec + (int64_t)2 * kCUs * 8 /* body + tail launches */ + (int64_t)kCUs * 8 * 10 /* diagnostic stamps */;
     w.total = w.slabs + hidden * (FP * FP + FP) * (int64_t)wgrad16_splits(d, n) + 2 * FP * 4 * (int64_t)wgrad16_skinny_splits(d, n);
     return w;
 }
@@ -1920,23 +1922,64 @@ static int launch_fused(const FusedArgs &fa, int grid, hipStream_t st)
 }
 
 template <bool TRAIN>
-static int launch_k16(const FusedArgs &fa, int grid, hipStream_t st)
+static int launch_k16(const FusedArgs &fa, int grid, hipStream_t st, int ns)
 {
     const int nt = brief_nt(fa.d);
-    static bool attr_done[2][2][2] = {{{false, false}, {false, false}}, {{false, false}, {false, false}}};
-#define BRIEF_CASE(NTV, COV)                                                                             \
-    if (nt == NTV && (fa.d.cout == 1) == (COV == 1)) {                                                   \
-        const size_t lds = sizeof(float) * Cfg16<NTV>::TOTAL;                                            \
-        if (!attr_done[NTV == 16][TRAIN][COV == 1]) {                                                    \
-            HIP_TRY(hipFuncSetAttribute((const void *)k16<NTV, TRAIN, COV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-            attr_done[NTV == 16][TRAIN][COV == 1] = true;                                                \
+    static bool attr_done[2][2][2][3] = {};
+    bool launched = false;
+#define BRIEF_CASE(NTV, COV, NSV)                                                                        \
+    if (!launched && nt == NTV && (fa.d.cout == 1) == (COV == 1) && ns == NSV) {                         \
+        const size_t lds = sizeof(float) * Cfg16<NTV, NSV>::TOTAL;                                       \
+        bool &done = attr_done[NTV == 16][TRAIN][COV == 1][NSV == 4 ? 2 : NSV - 1];                      \
+        if (!done) {                                                                                     \
+            HIP_TRY(hipFuncSetAttribute((const void *)k16<NTV, TRAIN, COV, NSV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            done = true;                                                                                 \
         }                                                                                                \
-        hipLaunchKernelGGL((k16<NTV, TRAIN, COV>), dim3(grid), dim3(512), lds, st, fa);                  \
+        hipLaunchKernelGGL((k16<NTV, TRAIN, COV, NSV>), dim3(grid), dim3(512), lds, st, fa);             \
+        launched = true;                                                                                 \
     }
     if (nt != 8 && nt != 16) return fail(BRIEF_ERR_INVALID, "unsupported width");
-    BRIEF_CASE(8, 1) BRIEF_CASE(8, 4) BRIEF_CASE(16, 1) BRIEF_CASE(16, 4)
+    BRIEF_CASE(8, 1, 4) BRIEF_CASE(8, 1, 2) BRIEF_CASE(8, 1, 1) BRIEF_CASE(8, 4, 4)
+    BRIEF_CASE(16, 1, 4) BRIEF_CASE(16, 1, 2) BRIEF_CASE(16, 1, 1) BRIEF_CASE(16, 4, 4)
 #undef BRIEF_CASE
+    if (!launched) return fail(BRIEF_ERR_INVALID, "no bf16 kernel for this configuration");
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// How a batch is cut into launches of k16: a body of whole rounds of 128-sample tiles (one per CU), then what is left
+// as quarter (NS = 1) or half (NS = 2) tiles when that spreads it over more CUs.  Multi-channel nets (CO = 4 kernels)
+// only exist with NS = 4.
+struct Split16 { int64_t n_body; int g_body, ns_tail, g_tail; };
+static Split16 split16(const brief_siren_desc &d, int64_t n)
+{
+    Split16 s;
+    const int64_t tiles = (n + 127) / 128;
+    const int64_t full = tiles / kCUs * kCUs, rem = tiles - full;
+    s.n_body = n; s.g_body = (int)(tiles < kCUs ? tiles : kCUs); s.ns_tail = 0; s.g_tail = 0;
+    if (d.cout != 1 || rem == 0) return s;
+    int ns = rem * 4 <= kCUs ? 1 : (rem * 2 <= kCUs ? 2 : 0);
+    if (!ns) return s;
+    s.n_body = full * 128;
+    s.g_body = full > 0 ? kCUs : 0;
+    s.ns_tail = ns;
+    s.g_tail = (int)((npad16(n) - s.n_body) / (32 * ns));          // tiles up to the padded size (see k16)
+    return s;
+}
+
+template <bool TRAIN>
+static int launch_k16_split(FusedArgs &fa, hipStream_t st)
+{
+    const Split16 sp = split16(fa.d, fa.n);
+    const int64_t np = npad16(fa.n);
+    if (sp.g_body > 0) {
+        fa.n_begin = 0; fa.n_end = sp.g_tail > 0 ? sp.n_body : np; fa.rec_base = 0;
+        if (int rc = launch_k16<TRAIN>(fa, sp.g_body, st, 4)) return rc;
+    }
+    if (sp.g_tail > 0) {
+        fa.n_begin = sp.n_body; fa.n_end = np; fa.rec_base = sp.g_body;
+        if (int rc = launch_k16<TRAIN>(fa, sp.g_tail, st, sp.ns_tail)) return rc;
+    }
     return 0;
 }
 
@@ -1974,7 +2017,7 @@ int brief_siren_forward(const brief_siren_desc *d, const float *packed, const br
     fa.span = (float)(vmax - vmin);
     fa.vmin = (float)vmin;
     fa.stagger_cus = kCUs; fa.stagger = 0;
-    if (d->precision == BRIEF_PREC_BF16) return launch_k16<false>(fa, grid16(batch->n), (hipStream_t)stream);
+    if (d->precision == BRIEF_PREC_BF16) return launch_k16_split<false>(fa, (hipStream_t)stream);
     return launch_fused<false>(fa, fused_grid(*d, batch->n, false), (hipStream_t)stream);
 }
 
@@ -2003,7 +2046,8 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
         const Ws16 w16 = ws16_layout(*d, batch->n);
         const int64_t np = npad16(batch->n), FP = 32 * nt;
         const int hidden = d->layers - 2;
-        const int g16 = grid16(batch->n), nsp = wgrad16_splits(*d, batch->n);
+        const Split16 sp16 = split16(*d, batch->n);
+        const int g16 = sp16.g_body + sp16.g_tail, nsp = wgrad16_splits(*d, batch->n);
         const float inv16 = (float)(1.0 / ((double)batch->n * d->cout));
         FusedArgs fa;
         memset(&fa, 0, sizeof(fa));
@@ -2017,7 +2061,7 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
         fa.S16[0] = ws + w16.h; fa.S16[1] = ws + w16.c; fa.S16[2] = ws + w16.dd; fa.S16[3] = ws + w16.x; fa.S16[4] = ws + w16.g;
         const bool prof16 = g_prof_on && g_prof_n < kProfSlots;
         if (prof16) HIP_TRY(hipEventRecord(g_prof_ev[2 * g_prof_n], st));
-        if (int rc = launch_k16<true>(fa, g16, st)) return rc;
+        if (int rc = launch_k16_split<true>(fa, st)) return rc;
         if (prof16) { HIP_TRY(hipEventRecord(g_prof_ev[2 * g_prof_n + 1], st)); ++g_prof_n; }
         Wgrad16Args wa;
         memset(&wa, 0, sizeof(wa));

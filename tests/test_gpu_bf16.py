@@ -33,8 +33,11 @@ def pair(L, F, cin=3, cout=1, seed=0):
 
 
 @pytest.mark.parametrize("L,F,cin,cout,n", [(3, 256, 3, 1, 1000), (5, 256, 3, 1, 5000), (5, 200, 3, 1, 777), (4, 100, 2, 3, 300),
-                                             (4, 512, 3, 1, 3000), (9, 512, 3, 1, 20000), (2, 300, 3, 1, 500), (6, 384, 3, 2, 129)])
+                                             (4, 512, 3, 1, 3000), (9, 512, 3, 1, 20000), (2, 300, 3, 1, 500), (6, 384, 3, 2, 129),
+                                             (4, 256, 3, 1, 10000), (4, 512, 3, 1, 12345), (3, 256, 3, 1, 35000), (4, 130, 3, 1, 33000)])
 def test_forward_and_gradients_track_fp32(L, F, cin, cout, n):
+    """the sizes walk every launch shape of k16: quarter tiles only (n <= 8192), half tiles only (<= 16384), one partial
+    round of full tiles, full rounds + quarter / half tiles (33 000 = 256 full tiles + 2 tiles; 35 000 = 256 + 18)"""
     m32, m16 = pair(L, F, cin, cout, seed=L * 1000 + F)
     g = torch.Generator().manual_seed(n)
     x = (torch.rand(n, cin, generator=g) * 2 - 1).to(DEV)
