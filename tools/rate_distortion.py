@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--ratios", type=float, nargs="+", default=[1024, 512, 256, 128, 64])
     ap.add_argument("--sample-size", type=int, default=100000)
     ap.add_argument("--ssim", action="store_true")
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32")
     ap.add_argument("--detail", type=int, default=64, help="1/f texture components added to the synthetic field (0 = the bench volume)")
     ap.add_argument("--out", type=str, default="")
     a = ap.parse_args()
@@ -52,7 +53,7 @@ def main():
             print("ratio %g needs %d features (> 512): skipped" % (ratio, F), flush=True)
             continue
         torch.manual_seed(42)
-        m = SIREN(coords_channel=3, data_channel=1, features=F, layers=a.layers, w0=a.w0).to("cuda")
+        m = SIREN(coords_channel=3, data_channel=1, features=F, layers=a.layers, w0=a.w0, precision=a.precision).to("cuda")
         fit = Fitter(m, tv, dims, sampler="randompoint", sample_size=a.sample_size, seed=42)
         done, t_fit = 0, 0.0
         for target in sorted(a.steps):
