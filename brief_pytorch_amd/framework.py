@@ -145,6 +145,19 @@ class NFGR:
         pp = cf.Decompress.postprocess
         return preprocess(data, pp.denoise.level, pp.denoise.close, pp.clip)
 
+    def decompress_divide(self, orig_sideinfos_path, module_save_dir, sideinfos_save_dir, opt=None):
+        """main.py:299-320: decode every block of a stored DivideTask artefact (steps{k}/compressed/{module,sideinfos}/
+        <block>/...) and paste the blocks back by the inclusive index ranges in their names.  `opt` defaults to this
+        object's options (the reference re-reads the YAML given on the command line)."""
+        orig = load_yaml(orig_sideinfos_path)
+        data_shape = list(orig["data_shape"])
+        opt = opt if opt is not None else _wrap(self.opt)
+        parts = []
+        for chunk_name in sorted(os.listdir(module_save_dir)):
+            dec = NFGR.decompress(opt, opj(module_save_dir, chunk_name, "module"), opj(sideinfos_save_dir, chunk_name, "sideinfos.yaml"), self.device)
+            parts.append({"data": dec, "name": chunk_name, **parse_chunk_name(chunk_name)})
+        return merge_divided_data(parts, data_shape)
+
     # ---- SingleTask encode (main.py:322-454)
     def prepare_fit(self, data_path, data=None, logdir=None):
         """everything main.py:322-384 sets up before the loop: preprocess, loss weights, normalise, size the

@@ -90,6 +90,9 @@ def test_dividetask_single_rank(tmp_path):
     merged = read_img(os.path.join(Log.logdir, "steps200", "decompressed", "blk_decompressed.tif"))
     d = merged.astype(np.float64) - vol.astype(np.float64)
     assert abs(-10 * np.log10((d * d).mean() / 65535.0 ** 2) - res[200]["psnr"]) < 1e-6
+    # decompress_divide (main.py:299-320): the stored artefact tree alone reproduces the merged volume bit for bit
+    again = fw.decompress_divide(os.path.join(cdir, "sideinfos.yaml"), os.path.join(cdir, "module"), os.path.join(cdir, "sideinfos"))
+    assert again.dtype == merged.dtype and np.array_equal(again, merged)
 
 
 def test_dividetask_cotrained_blocks_equal_serial_blocks(tmp_path, monkeypatch):
