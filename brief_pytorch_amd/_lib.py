@@ -44,7 +44,7 @@ class FitJob(C.Structure):          # brief_fit_job
                 ("gamma", C.c_double), ("t0", C.c_int64)]
 
 
-LOSS_KIND = {"datal2": 0, "datasmoothl1": 1}
+LOSS_KIND = {"datal2": 0, "datasmoothl1": 1, "external": 2}
 OPT_KIND = {"Adamax": 0, "Adam": 1, "SGD": 2}
 OUT_F32, OUT_U8, OUT_U16 = 0, 1, 2
 PRECISION = {"fp32": 0, "f32": 0, "bf16": 1}

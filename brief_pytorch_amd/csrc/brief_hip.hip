@@ -509,13 +509,13 @@ __global__ __launch_bounds__(256, TRAIN ? (NT > 8 ? 1 : BRIEF_TRAIN_WPE) : (NT >
                 const float df = yh[c] - yv[c];
                 float li, gi;
                 if (a.loss_kind == BRIEF_LOSS_L2) { li = df * df; gi = 2.0f * df; }
-                else {
+                else if (a.loss_kind == BRIEF_LOSS_SMOOTHL1) {
                     const float ad = fabsf(df);
                     if (ad < a.beta) { li = 0.5f * df * df / a.beta; gi = df / a.beta; }
                     else { li = ad - 0.5f * a.beta; gi = df < 0.f ? -1.0f : 1.0f; }
-                }
+                } else { li = 0.f; gi = 0.f; }
                 if (wm == 0 && hi == 0) lsum += li * we;
-                g[c] = gi * we * a.inv_count;
+                g[c] = a.loss_kind == BRIEF_LOSS_EXTERNAL ? yv[c] : gi * we * a.inv_count;      // external: targets ARE dL/dyhat
                 if (d.output_act) g[c] *= d.w0_hidden * brief_fast_cosf(d.w0_hidden * zo[c]);
                 if (a.yhat_out && wm == 0 && hi == 0) a.yhat_out[n * cout + c] = yh[c];
             }
@@ -877,13 +877,13 @@ __global__ __launch_bounds__(256, small_wpe(HB)) void k_small(const FusedArgs a)
                 const float df = yh[c] - yv[c];
                 float li, gi;
                 if (a.loss_kind == BRIEF_LOSS_L2) { li = df * df; gi = 2.0f * df; }
-                else {
+                else if (a.loss_kind == BRIEF_LOSS_SMOOTHL1) {
                     const float ad = fabsf(df);
                     if (ad < a.beta) { li = 0.5f * df * df / a.beta; gi = df / a.beta; }
                     else { li = ad - 0.5f * a.beta; gi = df < 0.f ? -1.0f : 1.0f; }
-                }
+                } else { li = 0.f; gi = 0.f; }
                 if (wm == 0 && hi == 0) lsum += li * we;
-                g[c] = gi * we * a.inv_count;
+                g[c] = a.loss_kind == BRIEF_LOSS_EXTERNAL ? yv[c] : gi * we * a.inv_count;      // external: targets ARE dL/dyhat
                 if (d.output_act) g[c] *= d.w0_hidden * brief_fast_cosf(d.w0_hidden * zo[c]);
                 if (a.yhat_out && wm == 0 && hi == 0) a.yhat_out[n * cout + c] = yh[c];
             }
@@ -2033,7 +2033,7 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
     if (int rc = check_desc(d)) return rc;
     if (int rc = check_batch(d, grid, batch, true)) return rc;
     if (!packed || !grads || !loss_out || !workspace) return fail(BRIEF_ERR_INVALID, "null buffer");
-    if (loss_kind != BRIEF_LOSS_L2 && loss_kind != BRIEF_LOSS_SMOOTHL1) return fail(BRIEF_ERR_INVALID, "bad loss_kind");
+    if (loss_kind < BRIEF_LOSS_L2 || loss_kind > BRIEF_LOSS_EXTERNAL) return fail(BRIEF_ERR_INVALID, "bad loss_kind");
     if (d->precision == BRIEF_PREC_BF16 ? (int64_t)32 * brief_nt(*d) * npad16(batch->n) * 2 >= ((int64_t)1 << 31)
                                        : (int64_t)32 * brief_nt(*d) * brief_npad(brief_nt(*d), batch->n) * 4 >= ((int64_t)1 << 31))
         return fail(BRIEF_ERR_INVALID, "batch too large for one train step (padded width x samples x 4 bytes must stay below 2 GiB): split it");

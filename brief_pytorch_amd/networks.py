@@ -85,6 +85,31 @@ class _Seq:
         return 1
 
 
+class _SirenFn(torch.autograd.Function):
+    """forward/backward of the module under torch autograd (main.py:391-396: `data_hat = phi.forward(x);
+    loss = loss_func(...); loss.backward()`).  backward hands dL/dyhat to the fused train step
+    (BRIEF_LOSS_EXTERNAL) and leaves the gradient in module.params.grad, where torch.optim looks for it."""
+
+    @staticmethod
+    def forward(ctx, anchor, coords, module):
+        ctx.module = module
+        ctx.save_for_backward(coords)
+        return module._forward_plain(coords)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (coords,) = ctx.saved_tensors
+        m = ctx.module
+        cin, cout = m.coords_channel, m.data_channel
+        n = coords.numel() // cin
+        m.train_step(n, gy.reshape(n, cout).to(torch.float32).contiguous(), coords=coords.reshape(n, cin), loss="external")
+        if m.params.grad is None:
+            m.params.grad = m.grads.clone()
+        else:
+            m.params.grad += m.grads
+        return gy.new_zeros(1), None, None
+
+
 class SIREN:
     """reference: utils/Networks.py:236-314."""
 
@@ -108,6 +133,9 @@ class SIREN:
         self.grads = None
         self.packed = None
         self._stale = True
+        self._seen_version = -1
+        self._autograd = False
+        self._anchor = None
         self._ws = None
         self._loss = None
         net, off = [], 0
@@ -187,6 +215,10 @@ class SIREN:
         return self
 
     def requires_grad_(self, flag=True):
+        """requires_grad_(True): forward() takes part in torch autograd (the reference's own loop body then runs on
+        this module: zero_grad, forward, loss, backward, torch.optim step).  Default off: forward() returns plain
+        tensors and the fused Fitter path is the fast one."""
+        self._autograd = bool(flag)
         return self
 
     @property
@@ -206,9 +238,12 @@ class SIREN:
             n = _lib.lib().brief_packed_count(C.byref(self.desc))
             self.packed = torch.empty(n, dtype=torch.float32, device=self.params.device)
             self._stale = True
+        if self.params._version != self._seen_version:      # torch changed the parameters in place (e.g. optimizer.step())
+            self._stale = True
         if self._stale:
             _lib.check(_lib.lib().brief_siren_repack(C.byref(self.desc), _lib.ptr(self.params), _lib.ptr(self.packed), _lib.stream_ptr()))
             self._stale = False
+            self._seen_version = self.params._version
 
     @staticmethod
     def _grid(dims, lo, hi):
@@ -220,7 +255,16 @@ class SIREN:
         return g
 
     def forward(self, coords):
-        """SIREN.forward (utils/Networks.py:269-271) without autograd: coords [..., cin] -> [..., cout]."""
+        """SIREN.forward (utils/Networks.py:269-271): coords [..., cin] -> [..., cout].  Differentiable w.r.t. the
+        parameters after requires_grad_(True) (see _SirenFn); otherwise a plain no-grad evaluation."""
+        if self._autograd and torch.is_grad_enabled():
+            self._require_gpu()
+            if self._anchor is None or self._anchor.device != self.params.device:
+                self._anchor = torch.zeros(1, device=self.params.device, requires_grad=True)
+            return _SirenFn.apply(self._anchor, coords.to(self.params.device, torch.float32).contiguous(), self)
+        return self._forward_plain(coords)
+
+    def _forward_plain(self, coords):
         self._require_gpu()
         self.sync_packed()
         c = coords.to(self.params.device, torch.float32).contiguous()
@@ -234,7 +278,8 @@ class SIREN:
                                                   _lib.OUT_F32, 0.0, 1.0, 0.0, 1.0, _lib.stream_ptr()))
         return out.view(*lead, self.data_channel)
 
-    __call__ = forward
+    def __call__(self, coords):
+        return self.forward(coords)
 
     def decode_grid(self, dims, lo=-1.0, hi=1.0, offset=0, count=None, out=None, out_kind="f32",
                     scale=(0.0, 100.0), vrange=(0.0, 1.0)):

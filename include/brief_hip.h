@@ -67,7 +67,11 @@ typedef struct {
     uint64_t rng_seed, rng_step;
 } brief_batch_desc;
 
-typedef enum { BRIEF_LOSS_L2 = 0, BRIEF_LOSS_SMOOTHL1 = 1 } brief_loss_kind;      /* main.py:176-191 */
+typedef enum {
+    BRIEF_LOSS_L2 = 0, BRIEF_LOSS_SMOOTHL1 = 1,      /* main.py:176-191 */
+    BRIEF_LOSS_EXTERNAL = 2   /* `targets` holds dL/dyhat per sample and channel (what autograd hands to the module's backward,
+                               * main.py:396 `loss.backward()`): it is used as is (no weights, no 1/N), loss_out receives 0 */
+} brief_loss_kind;
 typedef enum { BRIEF_OPT_ADAMAX = 0, BRIEF_OPT_ADAM = 1, BRIEF_OPT_SGD = 2 } brief_optim_kind; /* utils/misc.py:174-183 */
 typedef enum { BRIEF_OUT_F32 = 0, BRIEF_OUT_U8 = 1, BRIEF_OUT_U16 = 2 } brief_out_kind;
 

@@ -65,6 +65,50 @@ def test_singletask_matches_reference_run(tmp_path, golden):
     assert np.median(d) < 40
 
 
+@pytest.mark.parametrize("L,F", [(5, 256), (4, 40), (3, 300)])
+def test_reference_loop_body_runs_on_the_module(L, F):
+    """the reference's own loop body (main.py:385-400: zero_grad, forward, loss_func, backward, torch.optim step,
+    scheduler) on the duck-typed module: after requires_grad_(True) forward() is differentiable w.r.t. the parameters
+    (BRIEF_LOSS_EXTERNAL carries autograd's dL/dyhat into the fused backward) and torch.optim updates them in place."""
+    import torch.nn.functional as Fnn
+    from brief_pytorch_amd.fit import Fitter
+    torch.manual_seed(7)
+    a = SIREN(features=F, layers=L, w0=20).to("cuda")
+    torch.manual_seed(7)
+    b = SIREN(features=F, layers=L, w0=20).to("cuda")
+    dims = (12, 16, 20)
+    n = 12 * 16 * 20
+    g = torch.Generator().manual_seed(1)
+    y = (torch.rand(n, 1, generator=g) * 100).cuda()
+    lin = [torch.linspace(-1, 1, d) for d in dims]
+    x = torch.stack(torch.meshgrid(*lin, indexing="ij"), -1).reshape(1, *dims, 3).cuda()      # (1,d,h,w,3) as RandomCubeSampler yields
+    # reference-style loop on a
+    a.requires_grad_(True)
+    opt = torch.optim.Adamax(a.parameters(), lr=1e-3)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, [2, 3], 0.5)
+    ref_losses = []
+    for _ in range(5):
+        opt.zero_grad()
+        yhat = a.forward(x)
+        assert yhat.shape == (1, *dims, 1) and yhat.requires_grad
+        loss = Fnn.mse_loss(yhat, y.view(1, *dims, 1))
+        loss.backward()
+        if not ref_losses:
+            g_first = a.params.grad.clone()
+        opt.step()
+        sched.step()
+        ref_losses.append(float(loss.detach()))
+    # fused path on b: same data, same schedule
+    fit = Fitter(b, y, dims, sampler="full", optimizer="Adamax", lr=1e-3, scheduler={"name": "MultiStepLR", "milestones": [2, 3], "gamma": 0.5})
+    b.train_step(n, y, grid=(dims, -1.0, 1.0))
+    assert float((g_first - b.grads).abs().max()) <= 2e-5 * float(b.grads.abs().max())
+    fused_losses = [float(fit.step()) for _ in range(5)]
+    assert np.allclose(ref_losses, fused_losses, rtol=2e-5)
+    assert float((a.params - b.params).abs().max()) < 2e-5
+    with torch.no_grad():
+        assert not a.forward(x).requires_grad
+
+
 def test_dividetask_single_rank(tmp_path):
     from brief_pytorch_amd.synthetic import make_volume
     vol = make_volume((16, 32, 32), seed=3)
