@@ -145,6 +145,11 @@ class NFGR:
         pp = cf.Decompress.postprocess
         return preprocess(data, pp.denoise.level, pp.denoise.close, pp.clip)
 
+    def sample_nf(self, coords):
+        """main.py:266-268: the fitted network evaluated at `coords` without autograd"""
+        with torch.no_grad():
+            return self.module["phi"].forward(coords)
+
     def decompress_divide(self, orig_sideinfos_path, module_save_dir, sideinfos_save_dir, opt=None):
         """main.py:299-320: decode every block of a stored DivideTask artefact (steps{k}/compressed/{module,sideinfos}/
         <block>/...) and paste the blocks back by the inclusive index ranges in their names.  `opt` defaults to this

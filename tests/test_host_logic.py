@@ -100,3 +100,35 @@ def test_budget_drop_and_divide_num(golden):
     for d, h, w, nb, nd, nh, nw in g["divide_num"]:
         assert misc.cal_divide_num(int(d), int(h), int(w), int(nb), 1e6) == (nd, nh, nw)
     assert misc.cal_divide_num(64, 64, 64, -1, 4 * 1361 * 9.5) == tuple(g["divide_num_auto"])
+
+
+def test_coordinate_grids_match_the_reference(golden):
+    """create_coords / create_flattened_coords (utils/dataset.py:11-62): the axis values are the reference's
+    torch.linspace bit for bit (golden linspace_*), ordering is 'ij' with the last axis fastest"""
+    import torch
+    from brief_pytorch_amd.dataset import create_coords, create_flattened_coords
+    g = golden("decode")
+    for n in (2, 3, 16, 63, 64):
+        c = create_coords((n, 5), "-1,1")
+        assert c.shape == (n, 5, 2) and np.array_equal(c[:, 0, 0].numpy(), g["linspace_%d" % n])
+    f = create_flattened_coords((3, 4, 5), "n11")
+    assert f.shape == (60, 3)
+    assert np.array_equal(f.numpy(), g["flat_coords_3_4_5"])                       # the reference's own output
+    assert np.array_equal(create_flattened_coords((4, 6), "-1,1").numpy(), g["flat_coords_4_6"])
+    assert torch.equal(f[7], torch.tensor([-1.0, torch.linspace(-1, 1, 4)[1], torch.linspace(-1, 1, 5)[2]]))
+    assert torch.equal(create_flattened_coords((4, 5), "0p1")[6], torch.tensor([torch.linspace(0, 1, 4)[1], torch.linspace(0, 1, 5)[1]]))
+    with pytest.raises(NotImplementedError):
+        create_coords((2, 2, 2, 2))
+
+
+def test_reconstruct_flattened_chunks():
+    import torch
+    from brief_pytorch_amd.dataset import create_flattened_coords, reconstruct_flattened
+    calls = []
+
+    def nf(c):
+        calls.append(c.shape[0])
+        return c.sum(-1, keepdim=True)
+    out = reconstruct_flattened((3, 4, 5, 1), 16, nf, coords_mode="-1,1")
+    assert calls == [16, 16, 16, 12] and out.shape == (3, 4, 5, 1)
+    assert torch.equal(out.reshape(-1, 1), create_flattened_coords((3, 4, 5), "-1,1").sum(-1, keepdim=True))
