@@ -61,6 +61,7 @@ class Fitter:
         else:
             raise NotImplementedError("lr scheduler %r" % sch.get("name"))
         self.t = 0
+        self._sched_name = sch.get("name") or "none"
         self._milestones = sorted(int(v) for v in sch.get("milestones", [])) if sch.get("name") == "MultiStepLR" else []
         self._gamma = float(sch.get("gamma", 0.1)) if self._milestones else 1.0
         self._ms_arr = (C.c_int64 * max(len(self._milestones), 1))(*self._milestones)
@@ -71,6 +72,8 @@ class Fitter:
         job are kept alive by this object until the next call."""
         if self.index_stream is not None:
             raise _lib.BriefError("a replayed index stream needs step(): brief_siren_fit draws its indices in-kernel")
+        if self._sched_name == "StepLR":
+            raise _lib.BriefError("StepLR is applied by step()/run(); brief_fit_job carries MultiStepLR only")
         m = self.m
         m._require_gpu()
         m.sync_packed()
@@ -98,6 +101,11 @@ class Fitter:
     def run(self, steps, log=False):
         """`steps` optimizer steps in ONE C-ABI call (brief_siren_fit): same results, bit for bit, as calling
         step() that many times.  Returns the device loss of the last step, or the per-step loss tensor if log."""
+        if self._sched_name == "StepLR":
+            # closed-form schedule (lr * gamma^(epoch // step_size)), not the running product brief_siren_fit applies:
+            # keep it exact by stepping from here
+            losses = [self.step().clone() for _ in range(int(steps))]
+            return torch.cat(losses) if log else self.m._loss
         j, loss_log = self.job(steps, log)
         _lib.check(_lib.lib().brief_siren_fit(C.byref(j), int(steps), _lib.stream_ptr()))
         self.t += int(steps)

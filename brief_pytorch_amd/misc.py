@@ -200,3 +200,33 @@ def cal_divide_num(d, h, w, Nb, param_size):
                 if num > best_num or (num == best_num and var < best_var):
                     best, best_num, best_var = (nd, nh, nw), num, var
     return best
+
+
+def configure_optimizer(parameters, optimizer, lr):
+    """utils/misc.py:174-183: a torch optimizer over `parameters` (for code that keeps the reference's loop and uses
+    the module through autograd, see networks._SirenFn; the fused Fitter applies the same rules in-kernel)."""
+    import torch
+    if optimizer == "Adam":
+        return torch.optim.Adam(parameters, lr=lr)
+    if optimizer == "Adamax":
+        return torch.optim.Adamax(parameters, lr=lr)
+    if optimizer == "SGD":
+        return torch.optim.SGD(parameters, lr=lr)
+    raise NotImplementedError(optimizer)
+
+
+def configure_lr_scheduler(optimizer, lr_scheduler_opt):
+    """utils/misc.py:184-197"""
+    import copy
+    import torch
+    o = copy.deepcopy(dict(lr_scheduler_opt))
+    name = o.pop("name")
+    if name == "MultiStepLR":
+        return torch.optim.lr_scheduler.MultiStepLR(optimizer, **o)
+    if name == "CyclicLR":
+        return torch.optim.lr_scheduler.CyclicLR(optimizer, **o)
+    if name == "StepLR":
+        return torch.optim.lr_scheduler.StepLR(optimizer, **o)
+    if name == "none":
+        return torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones=[100000000000])
+    raise NotImplementedError(name)

@@ -366,6 +366,20 @@ def test_fit_many_steps_per_call_equals_single_steps(L, F, sampler, opt):
     assert torch.equal(a.m.packed, b.m.packed)
 
 
+def test_steplr_schedule_matches_torch():
+    """utils/misc.py:190-191 StepLR: lr_t = lr * gamma^((t-1) // step_size), also through run()"""
+    sched = {"name": "StepLR", "step_size": 4, "gamma": 0.5}
+    a = _mk_fitter(3, 32, (8, 8, 8), "full", 0, 3, sched)
+    b = _mk_fitter(3, 32, (8, 8, 8), "full", 0, 3, sched)
+    ref = torch.optim.lr_scheduler.StepLR(torch.optim.SGD([torch.zeros(1, requires_grad=True)], lr=1e-3), 4, 0.5)
+    for t in range(1, 11):
+        assert abs(a.lr_at(t) - ref.get_last_lr()[0]) < 1e-18
+        ref.optimizer.step(); ref.step()
+        a.step()
+    log = b.run(10, log=True)
+    assert b.t == 10 and log.shape == (10,) and torch.equal(a.m.params, b.m.params)
+
+
 def test_multi_fit_equals_individual_fits():
     """brief_multi_fit: blocks co-trained on internal streams give exactly the results of fitting each alone
     (10 jobs > 8 pool streams: two jobs share a stream)."""

@@ -132,3 +132,23 @@ def test_reconstruct_flattened_chunks():
     out = reconstruct_flattened((3, 4, 5, 1), 16, nf, coords_mode="-1,1")
     assert calls == [16, 16, 16, 12] and out.shape == (3, 4, 5, 1)
     assert torch.equal(out.reshape(-1, 1), create_flattened_coords((3, 4, 5), "-1,1").sum(-1, keepdim=True))
+
+
+def test_configure_optimizer_and_scheduler_mirror():
+    import torch
+    p = [torch.zeros(3, requires_grad=True)]
+    for name, cls in (("Adam", torch.optim.Adam), ("Adamax", torch.optim.Adamax), ("SGD", torch.optim.SGD)):
+        o = misc.configure_optimizer(p, name, 1e-3)
+        assert isinstance(o, cls) and o.param_groups[0]["lr"] == 1e-3
+    with pytest.raises(NotImplementedError):
+        misc.configure_optimizer(p, "LBFGS", 1.0)
+    o = misc.configure_optimizer(p, "Adamax", 1e-3)
+    s = misc.configure_lr_scheduler(o, {"name": "MultiStepLR", "milestones": [2, 4], "gamma": 0.2})
+    lrs = []
+    for _ in range(5):
+        lrs.append(o.param_groups[0]["lr"]); o.step(); s.step()
+    assert np.allclose(lrs, [1e-3, 1e-3, 2e-4, 2e-4, 4e-5])
+    assert isinstance(misc.configure_lr_scheduler(o, {"name": "none"}), torch.optim.lr_scheduler.MultiStepLR)
+    assert isinstance(misc.configure_lr_scheduler(o, {"name": "StepLR", "step_size": 3}), torch.optim.lr_scheduler.StepLR)
+    with pytest.raises(NotImplementedError):
+        misc.configure_lr_scheduler(o, {"name": "Cosine"})
