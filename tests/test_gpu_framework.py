@@ -109,6 +109,40 @@ def test_reference_loop_body_runs_on_the_module(L, F):
         assert not a.forward(x).requires_grad
 
 
+def test_singletask_2d_rgb_image(tmp_path):
+    """2-D RGB inputs (coords_channel = 2, data_channel = 3, uint8) through NFGR.compress / decompress"""
+    rng = np.random.default_rng(0)
+    yy, xx = np.meshgrid(np.linspace(0, 1, 48), np.linspace(0, 1, 64), indexing="ij")
+    img = np.stack([120 + 100 * np.sin(6 * xx + 2 * yy), 128 + 90 * np.cos(5 * yy), 100 + 80 * np.sin(4 * (xx + yy))], -1)
+    img = np.clip(img + rng.normal(0, 2, img.shape), 0, 255).astype(np.uint8)
+    path = str(tmp_path / "rgb.npy")
+    save_img(path, img)
+    assert read_img(path).shape == (48, 64, 3)
+    opt = _opt(tmp_path, 4000, "none", 4.0 * SIREN.calc_param_count(2, 3, 48, 4))
+    cf = opt.CompressFramework
+    cf.Module.phi.coords_channel, cf.Module.phi.data_channel, cf.Module.phi.layers = 2, 3, 4
+    cf.Compress.preprocess.clip = [0, 255]
+    cf.Decompress.postprocess.clip = [0, 255]
+    cf.Compress.loss.weight = ["value_255_255_1"]
+    cf.Compress.loss.weight_thres = 255
+    cf.Decompress.mip = False
+    Log = MyLogger(**opt.Log)
+    torch.manual_seed(42)
+    fw = NFGR(cf, Log=Log)
+    res = fw.compress(path)
+    assert res[4000]["psnr"] > 20
+    sdir = os.path.join(Log.logdir, "steps4000")
+    side = config.load(os.path.join(sdir, "compressed", "sideinfos.yaml"))
+    assert list(side["data_shape"]) == [48, 64, 3] and side["phi_features"] == 48 and side["dtype"] == "uint8"
+    assert os.path.exists(os.path.join(sdir, "compressed", "module", "weight-0-48-2")) and os.path.exists(os.path.join(sdir, "compressed", "module", "weight-3-3-48"))
+    dec = read_img(os.path.join(sdir, "decompressed", "rgb_decompressed.npy"))
+    assert dec.shape == img.shape and dec.dtype == np.uint8
+    again = NFGR.decompress(config.to_opt({"CompressFramework": cf}), os.path.join(sdir, "compressed", "module"), dict(side))
+    assert np.array_equal(again, dec)
+    d = dec.astype(np.float64) - img.astype(np.float64)
+    assert abs(-10 * np.log10((d * d).mean() / 255.0 ** 2) - res[4000]["psnr"]) < 1e-4       # cal_psnr works in float32
+
+
 def test_dividetask_single_rank(tmp_path):
     from brief_pytorch_amd.synthetic import make_volume
     vol = make_volume((16, 32, 32), seed=3)
