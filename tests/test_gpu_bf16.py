@@ -64,6 +64,25 @@ def test_forward_and_gradients_track_fp32(L, F, cin, cout, n):
     assert torch.equal(g16, m16.grads) and float(l16) == float(l16b)
 
 
+def test_bf16_output_act_and_smooth_l1():
+    """the head Sine (output_act, utils/Networks.py:260-261) and the smooth-L1 loss on the bf16 path"""
+    torch.manual_seed(11)
+    m32 = SIREN(features=256, layers=4, w0=20, output_act=True).to(DEV)
+    m16 = SIREN(features=256, layers=4, w0=20, output_act=True, precision="bf16").to(DEV)
+    with torch.no_grad():
+        m16.params.copy_(m32.params)
+    n = 2000
+    g = torch.Generator().manual_seed(2)
+    x = (torch.rand(n, 3, generator=g) * 2 - 1).to(DEV)
+    y = (torch.rand(n, 1, generator=g) * 2 - 1).to(DEV)
+    for loss, beta in (("datal2", 0.01), ("datasmoothl1", 0.5)):
+        l32, _ = m32.train_step(n, y, coords=x, loss=loss, beta=beta)
+        g32 = m32.grads.clone()
+        l16, _ = m16.train_step(n, y, coords=x, loss=loss, beta=beta)
+        assert abs(float(l16) - float(l32)) / abs(float(l32)) < 2e-3
+        assert rel(m16.grads, g32) < 3e-2, loss
+
+
 def test_bf16_layout_and_errors():
     L = _lib.lib()
     import ctypes as C
