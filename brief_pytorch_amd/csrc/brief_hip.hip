@@ -278,6 +278,9 @@ struct FusedLds {
     static constexpr int TOTAL = HW_OFF + 4 * K::FP + 4;
 };
 
+#ifndef BRIEF_KERNARG_RELOAD
+#define BRIEF_KERNARG_RELOAD 1
+#endif
 #ifndef BRIEF_TRAIN_WPE
 #define BRIEF_TRAIN_WPE 2   // waves per SIMD the TRAIN variant is register-allocated for
 #endif
@@ -348,8 +351,30 @@ __global__ __launch_bounds__(256, TRAIN ? (NT > 8 ? 1 : BRIEF_TRAIN_WPE) : (NT >
         const bool valid = n < a.n;
         // ---- sample inputs (every wave of the sample tile fetches them; they are tiny).  Targets and
         //      weights are fetched now although the loss needs them a whole forward pass later.
+        // The ~40 scalars this section needs (pointers, rng, grid dims and magics) are re-read from the kernarg
+        // segment every tile through an opaque pointer: kept live across the tile loop they are spilled to VGPR
+        // lanes and come back one v_readlane (a VALU instruction) at a time, ~450 per tile.
+#if BRIEF_KERNARG_RELOAD
+        typedef const __attribute__((address_space(4))) FusedArgs *kargs_f;
+        kargs_f ap = (kargs_f)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ap));
+        const int64_t *k_idx = ap->idx;
+        const float *k_tg = ap->targets, *k_wt = ap->weights, *k_co = ap->coords;
+        const uint64_t k_pop = ap->rng_pop, k_seed = ap->rng_seed, k_step = ap->rng_step;
+        const int64_t k_off = ap->offset;
+        GridArgs kg;
+        kg.ndim = ap->grid.ndim; kg.lo = ap->grid.lo; kg.hi = ap->grid.hi; kg.fast = ap->grid.fast;
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) { kg.dims[ax] = ap->grid.dims[ax]; kg.step[ax] = ap->grid.step[ax]; kg.magic[ax] = ap->grid.magic[ax]; }
+#else
+        const int64_t *k_idx = a.idx;
+        const float *k_tg = a.targets, *k_wt = a.weights, *k_co = a.coords;
+        const uint64_t k_pop = a.rng_pop, k_seed = a.rng_seed, k_step = a.rng_step;
+        const int64_t k_off = a.offset;
+        const GridArgs &kg = a.grid;
+#endif
         int64_t j = 0;
-        if (valid) j = a.idx ? a.idx[n] : (a.rng_pop ? philox_index(n, a.rng_pop, a.rng_seed, a.rng_step) : n + a.offset);
+        if (valid) j = k_idx ? k_idx[n] : (k_pop ? philox_index(n, k_pop, k_seed, k_step) : n + k_off);
         float x0 = 0.f, x1 = 0.f, x2 = 0.f;
         float yv[4] = {0.f, 0.f, 0.f, 0.f}, wv4[4] = {1.f, 1.f, 1.f, 1.f};
         if (valid) {
@@ -357,17 +382,17 @@ __global__ __launch_bounds__(256, TRAIN ? (NT > 8 ? 1 : BRIEF_TRAIN_WPE) : (NT >
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     if (c < cout) {
-                        yv[c] = a.targets[j * cout + c];
-                        if (a.weights) wv4[c] = a.weights[j * cout + c];
+                        yv[c] = k_tg[j * cout + c];
+                        if (k_wt) wv4[c] = k_wt[j * cout + c];
                     }
                 }
             }
-            if (a.coords) {
-                x0 = a.coords[j * cin];
-                x1 = a.coords[j * cin + 1];
-                if (cin == 3) x2 = a.coords[j * cin + 2];
+            if (k_co) {
+                x0 = k_co[j * cin];
+                x1 = k_co[j * cin + 1];
+                if (cin == 3) x2 = k_co[j * cin + 2];
             } else {
-                grid_coords(a.grid, cin, j, x0, x1, x2);
+                grid_coords(kg, cin, j, x0, x1, x2);
             }
         }
         f32x16 acc[K::MTW];
@@ -692,32 +717,45 @@ __global__ __launch_bounds__(256, TRAIN ? (NT > 8 ? 1 : BRIEF_TRAIN_WPE) : (NT >
 //     fold their dW at the end;  NT = 2: wave (wm, ws) owns dW tile (wm, ws) over both sample tiles;
 //   * one slab per workgroup and layer goes to k_reduce (same slab format as k_wgrad's).
 // inputs of sample n for the train kernels: coordinates, targets, loss weights (defaults past the end of the batch)
-__device__ __forceinline__ void small_inputs(const FusedArgs &a, int cin, int cout, int64_t n, float4 &xo, float4 &yo, float4 &wo)
+// (The scalars it needs are re-read from the kernarg segment through an opaque pointer at every call: kept live across a
+//  tile loop they get spilled to VGPR lanes and come back one v_readlane — a VALU instruction — at a time.)
+typedef const __attribute__((address_space(4))) FusedArgs *kargs_t;
+__device__ __forceinline__ void small_inputs(const FusedArgs &a_unused, int cin, int cout, int64_t n, float4 &xo, float4 &yo, float4 &wo)
 {
+    (void)a_unused;
+    kargs_t ap = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();      // FusedArgs is the kernels' only argument
+    asm volatile("" : "+s"(ap));
     float x0 = 0.f, x1 = 0.f, x2 = 0.f;
     float yv[4] = {0.f, 0.f, 0.f, 0.f}, wv4[4] = {1.f, 1.f, 1.f, 1.f};
-    if (n < a.n) {
-        const int64_t j = a.idx ? a.idx[n] : (a.rng_pop ? philox_index(n, a.rng_pop, a.rng_seed, a.rng_step) : n + a.offset);
-        if (!a.targets) {
+    if (n < ap->n) {
+        const int64_t *k_idx = ap->idx;
+        const float *k_tg = ap->targets, *k_wt = ap->weights, *k_co = ap->coords;
+        const uint64_t k_pop = ap->rng_pop;
+        const int64_t j = k_idx ? k_idx[n] : (k_pop ? philox_index(n, k_pop, ap->rng_seed, ap->rng_step) : n + ap->offset);
+        if (!k_tg) {
             // forward-only launch: no targets
         } else if (cout == 1) {
-            yv[0] = a.targets[j];
-            if (a.weights) wv4[0] = a.weights[j];
+            yv[0] = k_tg[j];
+            if (k_wt) wv4[0] = k_wt[j];
         } else {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 if (c < cout) {
-                    yv[c] = a.targets[j * cout + c];
-                    if (a.weights) wv4[c] = a.weights[j * cout + c];
+                    yv[c] = k_tg[j * cout + c];
+                    if (k_wt) wv4[c] = k_wt[j * cout + c];
                 }
             }
         }
-        if (a.coords) {
-            x0 = a.coords[j * cin];
-            x1 = a.coords[j * cin + 1];
-            if (cin == 3) x2 = a.coords[j * cin + 2];
+        if (k_co) {
+            x0 = k_co[j * cin];
+            x1 = k_co[j * cin + 1];
+            if (cin == 3) x2 = k_co[j * cin + 2];
         } else {
-            grid_coords(a.grid, cin, j, x0, x1, x2);
+            GridArgs kg;
+            kg.ndim = ap->grid.ndim; kg.lo = ap->grid.lo; kg.hi = ap->grid.hi; kg.fast = ap->grid.fast;
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) { kg.dims[ax] = ap->grid.dims[ax]; kg.step[ax] = ap->grid.step[ax]; kg.magic[ax] = ap->grid.magic[ax]; }
+            grid_coords(kg, cin, j, x0, x1, x2);
         }
     }
     xo = make_float4(x0, x1, x2, 0.f);
