@@ -64,6 +64,35 @@ def test_forward_and_gradients_track_fp32(L, F, cin, cout, n):
     assert torch.equal(g16, m16.grads) and float(l16) == float(l16b)
 
 
+def _random_cases16(k, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(k):
+        L = int(rng.integers(2, 10))
+        F = int(rng.choice([rng.integers(8, 257), rng.integers(257, 513)]))
+        n = int(rng.choice([rng.integers(1, 300), rng.integers(300, 9000), rng.integers(9000, 40000)]))
+        out.append((L, F, int(rng.choice([2, 3])), int(rng.choice([1, 1, 3])), n))
+    return out
+
+
+@pytest.mark.parametrize("L,F,cin,cout,n", _random_cases16(14, 42))
+def test_bf16_seeded_random_shapes_track_fp32(L, F, cin, cout, n):
+    m32, m16 = pair(L, F, cin, cout, seed=L * 999 + F + n)
+    g = torch.Generator().manual_seed(n + F)
+    x = (torch.rand(n, cin, generator=g) * 2 - 1).to(DEV)
+    y = (torch.rand(n, cout, generator=g) * 100).to(DEV)
+    o32, o16 = m32.forward(x), m16.forward(x)
+    assert float((o16 - o32).abs().max()) < 1e-2
+    l32, _ = m32.train_step(n, y, coords=x)
+    g32 = m32.grads.clone()
+    l16, _ = m16.train_step(n, y, coords=x)
+    g16 = m16.grads.clone()
+    assert abs(float(l16) - float(l32)) / float(l32) < 2e-4
+    assert rel(g16, g32) < 3e-2
+    l16b, _ = m16.train_step(n, y, coords=x)
+    assert torch.equal(g16, m16.grads) and float(l16) == float(l16b)
+
+
 def test_bf16_output_act_and_smooth_l1():
     """the head Sine (output_act, utils/Networks.py:260-261) and the smooth-L1 loss on the bf16 path"""
     torch.manual_seed(11)

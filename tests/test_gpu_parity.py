@@ -139,6 +139,45 @@ def test_narrow_nets_on_chip_path_vs_oracle(L, F, cin, cout, n):
     assert torch.equal(g1, m.grads) and loss.item() == loss2.item()      # fixed summation order: bit-reproducible
 
 
+def _random_cases(k, seed):
+    rng = np.random.default_rng(seed)
+    cases = []
+    for i in range(k):
+        L = int(rng.integers(2, 11))
+        F = int(rng.choice([rng.integers(1, 65), rng.integers(65, 257), rng.integers(257, 400)], p=[0.5, 0.35, 0.15]))
+        cin = int(rng.choice([2, 3]))
+        cout = int(rng.choice([1, 1, 2, 3, 4]))
+        n = int(rng.choice([rng.integers(1, 40), rng.integers(40, 700), rng.integers(700, 4000)]))
+        cases.append((L, F, cin, cout, n, bool(rng.integers(0, 4) == 0), str(rng.choice(["datal2", "datasmoothl1"])), bool(rng.integers(0, 2)), int(rng.integers(0, 3))))
+    return cases
+
+
+@pytest.mark.parametrize("L,F,cin,cout,n,oa,loss,use_w,thr_mode", _random_cases(40, 20261003))
+def test_seeded_random_shapes_vs_oracle(L, F, cin, cout, n, oa, loss, use_w, thr_mode):
+    """40 seeded random configurations (depth, width across all three train kernels' ranges, ragged batch sizes,
+    2-D / 3-D coordinates, 1-4 channels, head sine, both losses, weights, weight threshold): forward, loss and every
+    gradient against the oracle, and bit-reproducibility of the second run."""
+    m, d, p = make_net(L, F, 20.0, cin, cout, oa, seed=L * 1000 + F + n)
+    rng = np.random.default_rng(L * 7 + F * 3 + n)
+    x = rng.uniform(-1, 1, size=(n, cin)).astype(np.float32)
+    y = (rng.uniform(-1, 1, size=(n, cout)) if oa else rng.uniform(0, 100, size=(n, cout))).astype(np.float32)
+    w = np.where(rng.uniform(size=(n, cout)) < 0.5, 0.25, 1.0).astype(np.float32) if use_w else None
+    thr = [0.0, 30.0, -0.2][thr_mode] if not oa else [0.0, 0.3, -0.2][thr_mode]
+    beta = 0.5 if loss == "datasmoothl1" else 0.01
+    xt, yt = torch.from_numpy(x).to(DEV), torch.from_numpy(y).to(DEV)
+    wt = torch.from_numpy(w).to(DEV) if use_w else None
+    out = m.forward(xt).cpu().numpy()
+    ref = O.forward(d, p, x)
+    assert np.max(np.abs(out - ref)) <= 2e-5 * max(np.max(np.abs(ref)), 1e-3)
+    l1, _ = m.train_step(n, yt, coords=xt, weights=wt, loss=loss, thr=thr, beta=beta)
+    g1 = m.grads.clone()
+    lo, go, _, _ = O.loss_grad(d, p, x, y, w if use_w else np.ones_like(y), 1 if loss == "datasmoothl1" else 0, thr, beta)
+    assert abs(l1.item() - lo) <= 1e-5 * abs(lo) + 1e-9
+    _check_grads(m, d, go)
+    l2, _ = m.train_step(n, yt, coords=xt, weights=wt, loss=loss, thr=thr, beta=beta)
+    assert torch.equal(g1, m.grads) and l1.item() == l2.item()
+
+
 def test_train_step_is_deterministic_and_batch_split_linear():
     """Property tests at a larger size: two launches give identical bits (no atomics), and the
     gradient of a batch is the count-weighted sum of the gradients of its two halves."""
