@@ -21,9 +21,14 @@
 //                      panels for the weight-gradient GEMM and accumulates the skinny gradients
 //                      (first layer, head) itself.
 //   k_wgrad<NT>        dW_l = D_l * sin(w Z_{l-1})^T, split-K over sample chunks, fp32 slabs.
-//   k_reduce           deterministic slab/record reduction -> canonical gradient buffer + loss.
+//   k_small<NT,HB>     F <= 64 (what BRIEF's YAMLs produce): the whole train step without any HBM stash, z in
+//                      registers, dW accumulated in registers across the persistent tile loop.
+//   k_reduce           deterministic slab/record reduction -> canonical gradient buffer + loss
+//                      (+ fused optimizer and write-through to the fragment copies in brief_siren_fit_step).
 //   k_optim            Adamax / Adam / SGD elementwise update (bit-matches the oracle's rule).
-//   k_repack           canonical params -> fragment-ordered copies.
+//   k_repack           canonical params -> fragment-ordered copies (fp32, and bf16 when precision = BF16).
+//   brief_bf16.inc     k16 / k_wgrad16 / k_reduce16: the same path on v_mfma_f32_32x32x16_bf16 (BRIEF_PREC_BF16).
+//   k_sample, k_sse_u16, k_ssim_u16, k_deblock_edge: index stream, metrics and the deblocking filter.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
