@@ -67,8 +67,56 @@ def cpu_baseline(seconds_budget=20.0):
         el = time.perf_counter() - t0
         if el > seconds_budget or steps >= 8:
             break
-    return {"value": n * steps / el, "unit": "voxels/s", "cores": O.lib().oracle_num_threads(), "kind": "port",
-            "sample": "%d step(s) of %d samples, 4x256 SIREN fwd+loss+bwd+Adamax, oracle/siren_oracle.c (OpenMP)" % (steps, n)}
+    out = {"value": n * steps / el, "unit": "voxels/s", "cores": O.lib().oracle_num_threads(), "kind": "port",
+           "sample": "%d step(s) of %d samples, 4x256 SIREN fwd+loss+bwd+Adamax, oracle/siren_oracle.c (OpenMP)" % (steps, n)}
+    try:
+        out["torch_cpu"] = torch_cpu_baseline(x, y, p)
+    except Exception as e:      # informational only: the oracle line above is the baseline
+        out["torch_cpu"] = {"error": repr(e)[:120]}
+    return out
+
+
+def torch_cpu_baseline(x, y, p, seconds_budget=10.0):
+    """The same step as the reference runs it (nn.Linear + sin, F.mse_loss, autograd, torch.optim.Adamax:
+    utils/Networks.py:246-271, main.py:385-400), restated here and timed with CPU PyTorch on this host."""
+    import torch.nn as nn
+
+    class Sine(nn.Module):
+        def __init__(self, w0):
+            super().__init__()
+            self.w0 = w0
+
+        def forward(self, v):
+            return torch.sin(self.w0 * v)
+    layers = [nn.Linear(3, FEATURES), Sine(W0)]
+    for _ in range(LAYERS - 2):
+        layers += [nn.Linear(FEATURES, FEATURES), Sine(30.0)]
+    layers += [nn.Linear(FEATURES, 1)]
+    net = nn.Sequential(*layers)
+    with torch.no_grad():       # same parameters as the oracle run (canonical order: W, b per layer)
+        off = 0
+        for m in net:
+            if isinstance(m, nn.Linear):
+                nw = m.weight.numel()
+                m.weight.copy_(torch.from_numpy(p[off:off + nw].reshape(m.weight.shape))); off += nw
+                m.bias.copy_(torch.from_numpy(p[off:off + m.bias.numel()])); off += m.bias.numel()
+    opt = torch.optim.Adamax(net.parameters(), lr=1e-3)
+    xt, yt = torch.from_numpy(x), torch.from_numpy(y)
+    steps, t0 = 0, None
+    while True:
+        opt.zero_grad()
+        loss = torch.nn.functional.mse_loss(net(xt), yt)
+        loss.backward()
+        opt.step()
+        if t0 is None:
+            t0 = time.perf_counter()        # first step is the warm-up
+            continue
+        steps += 1
+        el = time.perf_counter() - t0
+        if el > seconds_budget or steps >= 6:
+            break
+    return {"value": x.shape[0] * steps / el, "unit": "voxels/s", "threads": torch.get_num_threads(),
+            "sample": "%d step(s) after 1 warm-up, torch %s CPU autograd" % (steps, torch.__version__)}
 
 
 def main():
