@@ -124,6 +124,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--preroll", type=int, default=200, help="untimed steps before the counted warm-up (clock ramp)")
+    ap.add_argument("--encode-steps", type=int, default=2000, help="total optimizer steps of the end-to-end encode figure / psnr_at_bitrate (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-psnr", action="store_true")
     ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
@@ -171,6 +173,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # untimed pre-roll: a fresh device needs a few hundred ms of load before its clocks and caches are steady; without
+    # it a short timed window (the driver's --steps 20 --warmup 5 = 30 ms) measures the ramp, not the kernel
+    t_pre = time.perf_counter()
+    pre = 0
+    while pre < args.preroll or time.perf_counter() - t_pre < 0.5:
+        fit.step()
+        pre += 1
+        if pre % 50 == 0:
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         fit.step()
     L = _lib.lib()
@@ -189,30 +200,54 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # ---- PSNR of the (briefly trained) net: decode the block, SSE all-reduce over ranks
-    psnr = None
+    # ---- end-to-end figures: continue the SAME fit to --encode-steps optimizer steps in one C-ABI call,
+    #      decode the whole block with the forward kernel (de-normalise + cast fused), PSNR from the GPU SSE
+    psnr, extra = None, {}
+    steps_done = pre + args.warmup + args.steps
     if not args.no_psnr:
+        more = max(args.encode_steps - steps_done, 0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        if more:
+            fit.run(more)
+        torch.cuda.synchronize()
+        t_more = time.perf_counter() - t1
+        steps_done += more
+        t2 = time.perf_counter()
         dec = net.decode_grid(BLOCK, out_kind="u16", scale=(0.0, 100.0), vrange=(vmin, vmax))
+        torch.cuda.synchronize()
+        t_dec = time.perf_counter() - t2
         sse = torch.zeros(1, dtype=torch.float64, device=dev)
         _lib.check(L.brief_sse_u16(_lib.ptr(vol), _lib.ptr(dec), vol.numel(), _lib.ptr(sse), _lib.stream_ptr()))
         red = torch.tensor([sse.item(), float(vol.numel())], dtype=torch.float64, device=red_dev)
         if dist is not None:
             dist.all_reduce(red)          # the one collective of the DivideTask path: [SSE, n]
         psnr = float(-10.0 * np.log10(red[0].item() / red[1].item() / 65535.0 ** 2))
+        nvox = float(np.prod(BLOCK))
+        ms_more = t_more * 1e3 / more if more else elapsed * 1e3 / args.steps
+        t_encode = steps_done * ms_more * 1e-3                  # every step of the fit at the measured steady rate
+        extra = {"encode": {"steps": steps_done, "seconds": t_encode, "voxels_per_s": nvox / t_encode, "ms_per_step": ms_more,
+                            "note": "whole 512^3 block / (steps x steady step time): sampler, optimizer and lr schedule included, checkpoints off"},
+                 "decode": {"seconds": t_dec, "voxels_per_s": nvox / t_dec, "tflops": nvox * flops_per_sample(LAYERS, FEATURES)[2] / t_dec / 1e12,
+                            "note": "decode_grid of the whole block: coordinates synthesised in-kernel, de-normalise + uint16 cast fused"}}
 
     if rank == 0:
-        # HBM traffic of the dominant kernel: PMC counters need rocprofv3, so the figure comes from the committed
-        # counter passes of this same command (profiles/r01_traffic.json: 2*FETCH_SIZE + WRITE_SIZE, per launch)
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-                traffic = float(json.load(f)["k_fused"]["hbm_bytes"])
-        except Exception:
-            pass
+        # HBM traffic of the dominant kernel: PMC counters need rocprofv3, so this figure is NOT measured in this run; it is
+        # read from the committed counter passes of this same command (tools/profile_round.sh: separate --pmc FETCH_SIZE /
+        # WRITE_SIZE passes, 2*FETCH_SIZE + WRITE_SIZE per launch, the guide's gfx950 correction) and labelled as such
+        traffic, traffic_src = None, None
+        for tag in ("r02", "r01"):
+            try:
+                with open(os.path.join(ROOT, "profiles", tag + "_traffic.json")) as f:
+                    traffic = float(json.load(f)["k_fused"]["hbm_bytes"])
+                traffic_src = "profiles/%s_traffic.json (static: rocprofv3 --pmc passes of this command, not this run)" % tag
+                break
+            except Exception:
+                pass
         train_f, fused_f, _ = flops_per_sample(LAYERS, FEATURES)
         peak = PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
         if args.precision != "fp32" or args.config != "c2":
-            traffic = None                  # the committed counter passes are for the default configuration only
+            traffic, traffic_src = None, None       # the committed counter passes are for the default configuration only
         fused_ms = tot_ms.value / max(launches.value, 1)
         achieved = fused_f * SAMPLE / (fused_ms * 1e-3) / 1e12
         ms_step = elapsed * 1e3 / args.steps
@@ -230,11 +265,13 @@ def main():
             "roofline": {"bound": "mfma", "kernel": ("k_fused<%d,true>" if args.precision == "fp32" else "k16<%d,true,1>") % (FEATURES // 32)
                          + " (forward+loss+dgrad)", "achieved": achieved,
                          "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": traffic, "kernel_ms": fused_ms, "flop_per_launch": fused_f * SAMPLE,
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": fused_ms, "flop_per_launch": fused_f * SAMPLE,
                          "step_tflops": train_f * SAMPLE / (ms_step * 1e-3) / 1e12,
                          "step_frac": train_f * SAMPLE / (ms_step * 1e-3) / 1e12 / peak},
-            "loss": float(loss.item()), "psnr_db": psnr, "psnr_after_steps": args.steps + args.warmup,
+            "loss": float(loss.item()), "preroll_steps": pre,
+            "psnr_at_bitrate": {"steps": steps_done, "bits_per_voxel": 32.0 * net.param_count / float(np.prod(BLOCK)), "psnr_db": psnr},
         }
+        out.update(extra)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

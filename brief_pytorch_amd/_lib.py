@@ -52,7 +52,8 @@ PRECISION = {"fp32": 0, "f32": 0, "bf16": 1}
 EXPORTS = ["brief_version", "brief_last_error", "brief_param_count", "brief_packed_count",
            "brief_train_workspace_bytes", "brief_siren_repack", "brief_siren_forward", "brief_siren_train_step", "brief_siren_fit_step",
            "brief_siren_fit", "brief_multi_fit",
-           "brief_optim_step", "brief_sample_indices", "brief_sse_u16", "brief_profile_enable", "brief_profile_fused", "brief_deblock_edge", "brief_ssim_u16", "brief_ssim_partial_count"]
+           "brief_optim_step", "brief_sample_indices", "brief_sse_u16", "brief_profile_enable", "brief_profile_fused", "brief_deblock_edge", "brief_ssim_u16", "brief_ssim_partial_count",
+           "brief_sincos_probe", "brief_cu_count"]
 
 
 def needs_build():
@@ -112,6 +113,8 @@ def lib():
     L.brief_ssim_partial_count.restype = C.c_int64
     L.brief_ssim_partial_count.argtypes = [C.c_int64] * 3
     L.brief_ssim_u16.argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_int64, vp, C.c_double, vp, C.c_int64, vp]
+    L.brief_sincos_probe.argtypes = [vp, vp, vp, C.c_int64, vp]
+    L.brief_cu_count.restype = C.c_int
     L.brief_profile_enable.argtypes = [C.c_int]
     L.brief_profile_fused.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     _LIB = L

@@ -1,28 +1,35 @@
-"""Adaptive octree partition (reference utils/adaptive_blocking.py:199-423, main.py:456-482)
+"""Adaptive octree / quadtree partition (reference utils/adaptive_blocking.py:60-423, main.py:456-482)
 without Gurobi.
 
-The reference builds a full octree of depth `maxl`, prunes nodes whose data is (near-)constant
+The reference builds a full 2^dim-ary tree of depth `maxl`, prunes nodes whose data is (near-)constant
 (variance <= var_thr and |mean| <= e_thr, together with all their descendants), gives every
 remaining node the feature  max|FFT| / sum|FFT|  (cal_feature), and solves a binary program:
 
-    maximise   sum_p  feature_p / 8^level_p * active_p
+    maximise   sum_p  feature_p / (2^dim)^level_p * active_p
     s.t.       sum_p active_p <= Nb
                active_p = 0                                  for level_p < minl
                exactly one active node on every root->leaf chain that has no pruned node,
-               at most one on chains that lost their tail to pruning.
+               at most one on chains that lost their tail to pruning (no row at all when fewer than
+               two nodes of the chain survive).
 
 That program is a tree knapsack.  `solve_tree` computes it exactly with a bottom-up DP
-(best[node][k] = best objective of the node's subtree with k active nodes), so no solver is
-needed.  Parity note: an ILP solver may return any optimal solution; the DP returns the one
-that prefers, on ties, fewer blocks and then the node itself over its children.  No golden
-vectors exist for this row (Gurobi is not available to run the reference's solver); the DP is
-validated by brute force on small trees (tests/test_adaptive_blocking.py).
+(best[node][k] = best objective of the node's subtree with k active nodes), so no solver is needed.
+
+Parity pin (tests/golden/adaptive.npz, tests/test_adaptive_blocking.py): the reference's OctTree was run
+with a recording stand-in for the gurobipy module; tree order, pruned-node set, every node's feature and
+the objective coefficients are compared with the reference's own, and the DP's optimum VALUE with the
+optimum of the reference's recorded program solved by an independent MILP solver (scipy / HiGHS).  An ILP
+solver may return any optimal solution; the DP returns the one that prefers, on ties, fewer blocks and
+then the node itself over its children.
+The 2-D branch of the reference cannot execute as shipped (QuadTree.get_feature reads an undefined
+self.Type, utils/adaptive_blocking.py:105; cal_feature has no branch for the 2-D gray patches it is handed,
+:16-24), so the quadtree here follows the octree's semantics with 4^level weights and is unpinned.
 """
 import math
 
 import numpy as np
 
-from .misc import cal_feature, chunk_name
+from .misc import cal_feature, chunk_name, rgb2gray
 
 NEG = -1.0e300
 
@@ -37,18 +44,23 @@ class Node:
         self.feature = 0.0
 
 
-def build_tree(shape, max_level):
-    """full octree; node (level, oz, oy, ox) covers a (d/2^l, h/2^l, w/2^l) box.  Child order matches
-    Patch3d.get_children (z outer, y, x inner)."""
-    d, h, w = shape[:3]
-    assert d % (2 ** max_level) == 0 and h % (2 ** max_level) == 0 and w % (2 ** max_level) == 0, "image size error!"
+def build_tree(shape, max_level, dim=3):
+    """full tree; node (level, oz, oy, ox) covers a (d/2^l, h/2^l, w/2^l) box (dim 2: d = 1, oz = 0).  Child order
+    matches Patch3d.get_children (z outer, y, x inner) / Patch2d.get_children (y outer, x inner)."""
+    if dim == 3:
+        d, h, w = shape[:3]
+        assert d % (2 ** max_level) == 0, "image size error!"
+    else:
+        d, (h, w) = 1, shape[:2]
+    assert h % (2 ** max_level) == 0 and w % (2 ** max_level) == 0, "image size error!"
 
     def make(level, oz, oy, ox):
         n = Node(level, oz, oy, ox)
-        n.d, n.h, n.w = d // 2 ** level, h // 2 ** level, w // 2 ** level
+        n.d = d // 2 ** level if dim == 3 else 1
+        n.h, n.w = h // 2 ** level, w // 2 ** level
         n.z, n.y, n.x = n.d * oz, n.h * oy, n.w * ox
         if level < max_level:
-            for i in range(2):
+            for i in range(2 if dim == 3 else 1):
                 for j in range(2):
                     for k in range(2):
                         n.children.append(make(level + 1, 2 * oz + i, 2 * oy + j, 2 * ox + k))
@@ -65,7 +77,20 @@ def iter_nodes(root):
         stack.extend(reversed(n.children))
 
 
-def prune_and_score(root, data, var_thr=0.0, e_thr=0.0, feature_fn=cal_feature):
+def _block(data, n, dim):
+    return data[n.z:n.z + n.d, n.y:n.y + n.h, n.x:n.x + n.w] if dim == 3 else data[n.y:n.y + n.h, n.x:n.x + n.w]
+
+
+def _feature2d(gray):
+    f = np.abs(np.fft.fft(np.fft.fft(gray, axis=0), axis=1))
+    return int(f.max()) / int(f.sum())
+
+
+def prune_and_score(root, data, var_thr=0.0, e_thr=0.0, feature_fn=None, dim=3):
+    """OctTree.prune (:341-352) then get_feature (:289-292)"""
+    if feature_fn is None:
+        feature_fn = cal_feature if dim == 3 else _feature2d
+
     def mark(n):
         n.pruned = True
         for c in n.children:
@@ -73,32 +98,31 @@ def prune_and_score(root, data, var_thr=0.0, e_thr=0.0, feature_fn=cal_feature):
     for n in iter_nodes(root):
         if n.pruned:
             continue
-        blk = data[n.z:n.z + n.d, n.y:n.y + n.h, n.x:n.x + n.w]
+        blk = _block(data, n, dim)
         m = blk.mean()
         if ((blk - m) ** 2).mean() <= var_thr and abs(m) <= e_thr:
             mark(n)
     for n in iter_nodes(root):
         if not n.pruned:
-            n.feature = float(feature_fn(data[n.z:n.z + n.d, n.y:n.y + n.h, n.x:n.x + n.w]))
+            n.feature = float(feature_fn(_block(data, n, dim)))
 
 
 def _maxplus(a, b, cap):
-    """c[k] = max_{i+j=k} a[i]+b[j], with the argmax i (k <= cap)"""
+    """c[k] = max_{i+j=k} a[i]+b[j], with the smallest maximising i (k <= cap)"""
     n = cap + 1
-    s = a[:, None] + b[None, :]                    # (i, j)
-    c = np.full(n, NEG)
-    arg = np.zeros(n, np.int64)
-    for k in range(n):
-        i = np.arange(0, k + 1)
-        v = s[i, k - i]
-        best = int(np.argmax(v))                   # first maximum: smallest i
-        c[k], arg[k] = v[best], best
-    return c, arg
+    i = np.arange(n)[:, None]
+    k = np.arange(n)[None, :]
+    j = k - i
+    s = np.where(j >= 0, a[:, None] + b[np.clip(j, 0, cap)], -np.inf)     # s[i, k]
+    arg = np.argmax(s, axis=0)                                             # first maximum: smallest i
+    c = s[arg, np.arange(n)]
+    return np.where(c < NEG / 2, NEG, c), arg.astype(np.int64)
 
 
-def solve_tree(root, Nb, min_level):
-    """exact DP; returns the list of active nodes (pre-order) or raises if infeasible"""
+def solve_tree(root, Nb, min_level, dim=3):
+    """exact DP; returns (active nodes in pre-order, objective value) or raises if infeasible"""
     cap = int(Nb)
+    fan = float(2 ** dim)
 
     def solve(n):
         # best[k]: best value with exactly k actives in this subtree, NO ancestor active
@@ -127,7 +151,7 @@ def solve_tree(root, Nb, min_level):
                 choice[k] = ("children", comb_splits)
         # option (a): node active (exactly one active on every chain through it)
         if n.level >= min_level and cap >= 1:
-            v = n.feature / (8.0 ** n.level)
+            v = n.feature / (fan ** n.level)
             if v >= best[1]:                       # tie -> the node itself
                 best[1] = v
                 choice[1] = ("self", None)
@@ -176,26 +200,45 @@ def adaptive_levels(Nb, param_size, dimension=3):
 
 
 def adaptive_chunk(data, param_size, divide_type):
-    """main.py:456-482 for 3-D data (d,h,w,1): returns (chunk list, outline volume)"""
+    """main.py:456-482: (d,h,w,1|3) volumes through the octree, (h,w,3|1) images through the quadtree.
+    Returns (chunk list, outline)."""
     _, _maxl, _minl, var_thr, e_thr, Nb = divide_type.split("_")
     var_thr, e_thr, Nb = int(var_thr), int(e_thr), int(Nb)
-    if data.ndim != 4 or data.shape[-1] != 1:
-        raise NotImplementedError("adaptive partition is implemented for single-channel 3-D data")
-    Nb, minl, maxl = adaptive_levels(Nb, param_size, 3)
-    root = build_tree(data.shape, maxl)
-    prune_and_score(root, data, var_thr, e_thr)
-    active, _ = solve_tree(root, Nb, minl)
+    if data.ndim == 4:
+        dim = 3
+        tree_data = data
+        if data.shape[-1] == 3:                      # adaptive_cal_tree: per-slice RGB -> gray (:388-392)
+            tree_data = rgb2gray(data, "rgb")[..., None]
+        elif data.shape[-1] != 1:
+            raise NotImplementedError("adaptive partition needs 1 or 3 channels")
+    elif data.ndim == 3:
+        dim = 2
+        tree_data = rgb2gray(data, "rgb") if data.shape[-1] == 3 else data[..., 0]
+    else:
+        raise NotImplementedError("adaptive partition needs (d,h,w,c) or (h,w,c) data")
+    Nb, minl, maxl = adaptive_levels(Nb, param_size, dim)
+    root = build_tree(tree_data.shape, maxl, dim)
+    prune_and_score(root, tree_data, var_thr, e_thr, dim=dim)
+    active, _ = solve_tree(root, Nb, minl, dim)
     outline = data.copy()
     chunks = []
     for p in active:
         z, y, x, d, h, w = p.z, p.y, p.x, p.d, p.h, p.w
-        c = {"data": data[z:z + d, y:y + h, x:x + w], "d": [z, z + d - 1], "h": [y, y + h - 1], "w": [x, x + w - 1]}
+        if dim == 3:
+            c = {"data": data[z:z + d, y:y + h, x:x + w], "d": [z, z + d - 1], "h": [y, y + h - 1], "w": [x, x + w - 1]}
+            faces = ((z, slice(y, y + h), slice(x, x + w)), (z + d - 1, slice(y, y + h), slice(x, x + w)),
+                     (slice(z, z + d), y, slice(x, x + w)), (slice(z, z + d), y + h - 1, slice(x, x + w)),
+                     (slice(z, z + d), slice(y, y + h), x), (slice(z, z + d), slice(y, y + h), x + w - 1))
+            for sl in faces:
+                outline[sl] = 2000
+        else:
+            c = {"data": data[y:y + h, x:x + w], "h": [y, y + h - 1], "w": [x, x + w - 1]}
+            col = np.array([0, 0, 255] if data.shape[-1] == 3 else [255], data.dtype)   # cv2.rectangle(..., (0,0,255), 2)
+            for sl in ((slice(y, y + 2), slice(x, x + w)), (slice(y + h - 2, y + h), slice(x, x + w)),
+                       (slice(y, y + h), slice(x, x + 2)), (slice(y, y + h), slice(x + w - 2, x + w))):
+                outline[sl] = col
         c["total_size"], c["size"] = data.size, c["data"].size
         c["name"] = chunk_name(c)
         chunks.append(c)
-        for sl in ((z, slice(y, y + h), slice(x, x + w)), (z + d - 1, slice(y, y + h), slice(x, x + w)),
-                   (slice(z, z + d), y, slice(x, x + w)), (slice(z, z + d), y + h - 1, slice(x, x + w)),
-                   (slice(z, z + d), slice(y, y + h), x), (slice(z, z + d), slice(y, y + h), x + w - 1)):
-            outline[sl] = 2000
     print("total numbers of the chunks: " + str(len(chunks)))
     return chunks, outline

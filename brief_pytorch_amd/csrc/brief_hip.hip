@@ -1776,8 +1776,22 @@ static int g_prof_n = 0;
 static hipEvent_t g_prof_ev[2 * kProfSlots];
 static bool g_prof_init = false;
 
-static const int kMaxFusedGrid = 512;   // 2 resident workgroups per CU on 256 CUs
-static const int kWgradBlocks = 256;
+// compute units of the device the calling thread is on (256 on a whole MI355X; fewer on a partitioned one).  Grids,
+// workspace layout and the start stagger are sized from it, queried once per device.
+static int cu_count()
+{
+    static int cached[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
+#define kCUs cu_count()
+#define kWgradBlocks cu_count()
 
 // persistent grid: g_wg_per_cu workgroups per CU, each walking tiles blockIdx, blockIdx+grid, ...
 // scalars prepared in double exactly as oracle_optim_step / torch do
@@ -1791,9 +1805,17 @@ static OptimScalars optim_scalars(int kind, double lr, double beta1, double beta
     return o;
 }
 
-static const int kCUs = 256;            // MI355X
-static int g_wg_per_cu = BRIEF_TRAIN_WPE;   // resident k_fused<TRAIN> workgroups per CU
-static int g_stagger = 1;               // start delay per residency slot, units of s_sleep(127)
+// diagnostic knobs, read from the environment once: BRIEF_WG_PER_CU (resident k_fused<TRAIN> workgroups per CU),
+// BRIEF_STAGGER (start delay per residency slot, units of s_sleep(127))
+static int env_int(const char *name, int dflt, int lo, int hi)
+{
+    const char *e = getenv(name);
+    if (!e) return dflt;
+    const int v = atoi(e);
+    return v >= lo && v <= hi ? v : dflt;
+}
+static const int g_wg_per_cu = env_int("BRIEF_WG_PER_CU", BRIEF_TRAIN_WPE, 1, 4);
+static const int g_stagger = env_int("BRIEF_STAGGER", 1, 0, 64);
 static int fused_grid(const brief_siren_desc &d, int64_t n, bool train)
 {
     (void)train;
@@ -2146,8 +2168,6 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
         HIP_TRY(hipGetLastError());
         return 0;
     }
-    if (const char *e = getenv("BRIEF_WG_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 4) g_wg_per_cu = v; }
-    if (const char *e = getenv("BRIEF_STAGGER")) g_stagger = atoi(e);
     const bool small = use_small(*d);
     const int grid1 = small ? small_grid(*d, batch->n) : fused_grid(*d, batch->n, true);
     const int nsplit = small ? (d->layers > 2 ? grid1 : 0) : wgrad_splits(*d, batch->n);
@@ -2357,6 +2377,25 @@ int brief_profile_fused(double *total_ms, int64_t *launches)
     *launches = g_prof_n;
     return 0;
 }
+
+__global__ void k_sincos_probe(const float *__restrict__ x, float *__restrict__ s, float *__restrict__ c, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float sv, cv;
+    brief_fast_sincosf(x[i], &sv, &cv);
+    s[i] = sv; c[i] = cv;
+}
+
+int brief_sincos_probe(const float *x, float *s, float *c, int64_t n, void *stream)
+{
+    if (!x || !s || !c || n < 1) return fail(BRIEF_ERR_INVALID, "bad probe arguments");
+    hipLaunchKernelGGL(k_sincos_probe, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, s, c, n);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int brief_cu_count(void) { return cu_count(); }
 
 int brief_deblock_edge(uint16_t *img, int64_t D, int64_t H, int64_t W, int z1, int z2, int fixed, int a1, int a2, int vertical,
                        double index_a, double index_b, double thres, int mode, void *stream)

@@ -36,6 +36,11 @@ class Fitter:
                  sample_size=100000, optimizer="Adamax", lr=1e-3, scheduler=None, loss="datal2", thr=0.0, beta=0.01,
                  seed=42, index_stream=None):
         self.m = module
+        for what, t in (("targets", targets), ("weights", weights)):
+            # the kernels read these through raw pointers as contiguous f32 (a float64 weight map, e.g. parse_weight's
+            # 'exp_x_v' on integer data, would be silently reinterpreted)
+            if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or t.device != module.params.device):
+                raise _lib.BriefError("%s must be a contiguous float32 tensor on %s (got %s on %s)" % (what, module.params.device, t.dtype, t.device))
         self.targets = targets              # [pop, cout] f32 on device (normalised)
         self.weights = weights              # [pop, cout] f32 or None (all ones elided)
         self.dims = tuple(int(v) for v in dims)

@@ -466,28 +466,30 @@ def _append_csv(path, row):
 
 
 class _CubeIndexStream:
-    """RandomCubeSampler with windows smaller than the volume (main.py:38-125): every step draws
-    cube_count window origins uniformly and yields the flat voxel indices of those windows."""
+    """RandomCubeSampler with windows smaller than the volume (main.py:38-125): `unfold` enumerates the
+    prod(dims - cube_len + 1) window origins in row-major order (d slowest); every step draws cube_count of them with
+    torch.randint on the GLOBAL CPU generator (main.py:112, seeded by reproduc) and yields the flat voxel indices of
+    those windows, window after window, (ds, hs, ws) row-major inside a window.  Pinned: tests/golden/cube.npz."""
 
-    def __init__(self, dims, cube_len, cube_count, device, seed=42):
+    def __init__(self, dims, cube_len, cube_count, device, generator=None):
         self.dims, self.cl, self.count = list(dims), list(cube_len), int(cube_count)
         self.n = self.count * int(np.prod(self.cl))
-        self.gen = torch.Generator(device="cpu").manual_seed(seed)
+        self.gen = generator                 # None: the global generator, as the reference
         self.device = device
         grids = torch.meshgrid(*[torch.arange(c) for c in self.cl], indexing="ij")
         strides = [int(np.prod(self.dims[a + 1:])) for a in range(len(self.dims))]
         self.local = sum(g.reshape(-1) * s for g, s in zip(grids, strides))
         self.strides = strides
+        self.pops = [self.dims[a] - self.cl[a] + 1 for a in range(len(self.dims))]
+        self.pop_size = int(np.prod(self.pops))
 
     def __call__(self, t):
-        pops = [self.dims[a] - self.cl[a] + 1 for a in range(len(self.dims))]
-        pop = int(np.prod(pops))
-        win = torch.randint(0, pop, (self.count,), generator=self.gen)
+        win = torch.randint(0, self.pop_size, (self.count,), generator=self.gen)
         idx = []
         for wv in win.tolist():
             org, rem = 0, wv
-            for a in reversed(range(len(pops))):
-                org += (rem % pops[a]) * self.strides[a]
-                rem //= pops[a]
+            for a in reversed(range(len(self.pops))):
+                org += (rem % self.pops[a]) * self.strides[a]
+                rem //= self.pops[a]
             idx.append(self.local + org)
         return torch.cat(idx).to(self.device)

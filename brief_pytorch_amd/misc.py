@@ -126,11 +126,26 @@ def divide_data(data, divide_type):
     return chunks, outline
 
 
+def rgb2gray(img, order="rgb"):
+    """cv2.cvtColor(img, COLOR_RGB2GRAY / COLOR_BGR2GRAY) for integer images: OpenCV's 14-bit fixed-point weights
+    (R 4899, G 9617, B 1868) with rounding.  cv2 is not in this image, so this restatement is unpinned."""
+    r, g, b = (img[..., 0], img[..., 1], img[..., 2]) if order == "rgb" else (img[..., 2], img[..., 1], img[..., 0])
+    if np.issubdtype(img.dtype, np.integer):
+        y = (r.astype(np.int64) * 4899 + g.astype(np.int64) * 9617 + b.astype(np.int64) * 1868 + 8192) >> 14
+        return y.astype(img.dtype)
+    return (0.299 * r + 0.587 * g + 0.114 * b).astype(img.dtype)
+
+
 def cal_feature(image):
-    """utils/adaptive_blocking.py:16-24 for 3-D (d,h,w,c) data: max|FFT| / sum|FFT| (both truncated to int)"""
-    if image.ndim != 4:
-        raise NotImplementedError("2-D cal_feature needs an RGB->gray conversion (cv2) that this build does not carry")
-    f = np.abs(np.fft.fft(np.fft.fft(np.fft.fft(image, axis=0), axis=1), axis=2))
+    """utils/adaptive_blocking.py:16-24: max|FFT| / sum|FFT| (both truncated to int); (d,h,w,c) data -> 3-D FFT,
+    (h,w,3) images -> BGR2GRAY then 2-D FFT"""
+    if image.ndim == 3:
+        gray = rgb2gray(image, "bgr") if image.shape[-1] == 3 else image[..., 0]
+        f = np.abs(np.fft.fft(np.fft.fft(gray, axis=0), axis=1))
+    elif image.ndim == 4:
+        f = np.abs(np.fft.fft(np.fft.fft(np.fft.fft(image, axis=0), axis=1), axis=2))
+    else:
+        raise NotImplementedError("cal_feature needs (h,w,c) or (d,h,w,c) data")
     return int(f.max()) / int(f.sum())
 
 

@@ -321,9 +321,9 @@ class SIREN:
         if coords is None:
             dims, lo, hi = grid
             g = self._grid(dims, lo, hi)
-        b = _lib.BatchDesc(_lib.ptr(coords).value if coords is not None else None, targets.data_ptr(),
-                           weights.data_ptr() if weights is not None else None,
-                           idx.data_ptr() if idx is not None else None, int(offset), int(n), 0, 0, 0)
+        b = _lib.BatchDesc(_dev_ptr(coords, torch.float32, "coords", dev), _dev_ptr(targets, torch.float32, "targets", dev),
+                           _dev_ptr(weights, torch.float32, "weights", dev), _dev_ptr(idx, torch.int64, "idx", dev),
+                           int(offset), int(n), 0, 0, 0)
         _lib.check(_lib.lib().brief_siren_train_step(
             C.byref(self.desc), _lib.ptr(self.packed), C.byref(g) if g is not None else None, C.byref(b),
             _lib.LOSS_KIND[loss], float(thr), float(beta), _lib.ptr(self.grads), _lib.ptr(self._loss), _lib.ptr(yhat),
@@ -340,8 +340,9 @@ class SIREN:
         dims, lo, hi = grid
         g = self._grid(dims, lo, hi)
         pop, seed, step = rng if (rng is not None and idx is None) else (0, 0, 0)      # rng = (pop, seed, step): in-kernel sampling
-        b = _lib.BatchDesc(None, targets.data_ptr(), weights.data_ptr() if weights is not None else None,
-                           idx.data_ptr() if idx is not None else None, int(offset), int(n), int(pop), int(seed), int(step))
+        dev = self.params.device
+        b = _lib.BatchDesc(None, _dev_ptr(targets, torch.float32, "targets", dev), _dev_ptr(weights, torch.float32, "weights", dev),
+                           _dev_ptr(idx, torch.int64, "idx", dev), int(offset), int(n), int(pop), int(seed), int(step))
         _lib.check(_lib.lib().brief_siren_fit_step(
             C.byref(self.desc), _lib.ptr(self.params), _lib.ptr(self.packed), C.byref(g), C.byref(b),
             _lib.LOSS_KIND[loss], float(thr), float(beta), int(opt_kind), _lib.ptr(s1), _lib.ptr(s2),
@@ -365,27 +366,39 @@ class SIREN:
     # ---- budget -> width (utils/Networks.py:291-314)
     @staticmethod
     def calc_param_count(coords_channel, data_channel, features, layers, res=False, **kwargs):
-        if res:
-            param_count = coords_channel * features + features + 2 * (layers - 2) * (features ** 2 + features) + features * data_channel + data_channel
-        else:
-            param_count = coords_channel * features + features + (layers - 2) * (features ** 2 + features) + features * data_channel + data_channel
-        return int(param_count)
+        """utils/Networks.py:291-297: first layer + (layers-2) hidden F x F layers + head, weights and biases"""
+        SIREN._no_res(res)
+        F, hidden = features, layers - 2
+        return int((coords_channel + 1) * F + hidden * (F + 1) * F + (F + 1) * data_channel)
 
     @staticmethod
     def calc_features(param_count, coords_channel, data_channel, layers, res=False, **kwargs):
+        """utils/Networks.py:299-314: the positive root of hidden F^2 + (cin + 1 + hidden + cout) F + cout = P, rounded"""
+        SIREN._no_res(res)
+        hidden = layers - 2
+        lin = coords_channel + 1 + hidden + data_channel
+        if hidden == 0:
+            return round((param_count - data_channel) / lin)
+        return round((math.sqrt(lin * lin + 4 * hidden * (param_count - data_channel)) - lin) / (2 * hidden))
+
+    @staticmethod
+    def _no_res(res):
         if res:
-            a = (layers - 2) * 2
-            b = coords_channel + 1 + 2 * layers - 4 + data_channel
-            c = -param_count + data_channel
-        else:
-            a = layers - 2
-            b = coords_channel + 1 + layers - 2 + data_channel
-            c = -param_count + data_channel
-        if a == 0:
-            features = round(-c / b)
-        else:
-            features = round((-b + math.sqrt(b ** 2 - 4 * a * c)) / (2 * a))
-        return features
+            raise NotImplementedError("SIREN(res=True) is unsupported on the fused path")
+
+
+def _dev_ptr(t, dtype, what, device):
+    """data_ptr() of a tensor the C-ABI will read as `dtype`: wrong dtype / layout / device is an error here, not
+    silently reinterpreted bits in the kernel"""
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor) or t.dtype != dtype:
+        raise _lib.BriefError("%s must be a %s tensor (got %s)" % (what, dtype, getattr(t, "dtype", type(t))))
+    if not t.is_contiguous():
+        raise _lib.BriefError("%s must be contiguous" % what)
+    if t.device != device:
+        raise _lib.BriefError("%s must live on %s (got %s)" % (what, device, t.device))
+    return t.data_ptr()
 
 
 def get_nnmodule_param_count(module):

@@ -4,8 +4,10 @@
  * Python object returned by init_phi() (utils/Networks.py:795-802) and the loop body in
  * main.py:385-400.  Each entry point below names the reference code it replaces.  All pointers
  * are DEVICE pointers (e.g. torch.Tensor.data_ptr()), `stream` is a hipStream_t passed as
- * void*; nothing is allocated, freed or synchronised inside, so calls can be captured in a
- * hipGraph.  Every function returns 0 on success or a negative brief_status; the message of the
+ * void*.  The compute entry points only enqueue kernels on `stream`: no device memory is allocated or freed and the
+ * host never waits (exceptions, all outside the per-step path: brief_multi_fit creates its internal stream pool on
+ * first use and forks / joins it with events; brief_profile_* record and wait for events; brief_sse_u16 issues a
+ * hipMemsetAsync).  Every function returns 0 on success or a negative brief_status; the message of the
  * last failure on the calling thread is available through brief_last_error().
  */
 #ifndef BRIEF_HIP_H
@@ -187,6 +189,14 @@ int brief_deblock_edge(uint16_t *img, int64_t D, int64_t H, int64_t W, int z1, i
  * brief_profile_fused waits for them and returns the summed duration and the launch count. */
 int brief_profile_enable(int on);
 int brief_profile_fused(double *total_ms, int64_t *launches);
+
+/* diagnostics: the kernels' sine / cosine (two-term reduction to revolutions + v_sin_f32 / v_cos_f32, csrc/brief_math.h)
+ * evaluated elementwise on device: s[i] = sin(x[i]), c[i] = cos(x[i]).  tests/test_sincos_host.py measures it against
+ * float64 (Sine.forward of the reference goes through torch's ~1-ulp sin, utils/Networks.py:227-234). */
+int brief_sincos_probe(const float *x, float *s, float *c, int64_t n, void *stream);
+
+/* compute units of the current device as the library sized its grids and workspaces from (256 on a whole MI355X) */
+int brief_cu_count(void);
 
 #ifdef __cplusplus
 }

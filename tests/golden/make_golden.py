@@ -69,7 +69,7 @@ from utils import dataset as refdataset  # noqa: E402
 from utils.adaptive_blocking import cal_divide_num, cal_feature  # noqa: E402
 from brief_pytorch_amd.synthetic import make_volume  # noqa: E402  (this repo's generator)
 
-torch.set_num_threads(1)  # fixed reduction order
+torch.set_num_threads(int(os.environ.get("BRIEF_GOLDEN_THREADS", "1")))  # 1 = fixed reduction order (the long half/f32 fits may use more)
 
 
 class AttrDict(dict):
@@ -514,7 +514,280 @@ def g_deblock():
     save("deblock", img=img, names=np.array(names), lines=np.array(lines), out=out, out2=out2)
 
 
+# ----------------------------------------------------------------------------- 10. Compress.half (fp16) mode
+def g_half():
+    """The reference's own low-precision mode (main.py:388-399: module.half() for forward/backward, .float() for the
+    optimizer step) against its fp32 mode from the same seed on the same volume: loss traces and end-of-fit PSNR.
+    This anchors the band the MI355X low-precision path (bf16 MFMA, fp32 master weights) is held to."""
+    arrs = {}
+    vol = make_volume((24, 32, 40), seed=44)
+    steps, L_, F_ = 3000, 5, 128            # a wide-ish net to the end of a 3000-step fit (SURVEY Appendix F's horizon)
+    for tag, half in (("f32", False), ("f16", True)):
+        opt = load_opt()
+        cf = opt.CompressFramework
+        cf.Compress.gpu = False
+        cf.Decompress.gpu = False
+        cf.Module.phi.layers = L_
+        cf.Module.phi.w0 = 20
+        cf.Compress.sampler.name = "randomcube"
+        cf.Compress.half = False           # budget rule of the fp32 run for both (same net), the half flag only drives the loop
+        refmain.reproduc(opt.Reproduc)
+        nf = refmain.NFGR(cf)
+        nf.device = "cpu"
+        weight = refmisc.parse_weight(vol, cf.Compress.loss.weight)
+        data, side = refio.normalize_data(vol, **cf.Normalize)
+        feats, _ = nf.prepare_module(4.0 * SIREN.calc_param_count(3, 1, F_, L_, False))
+        assert feats == F_
+        if tag == "f32":
+            for k, v in state_arrays(nf.module["phi"]).items():
+                arrs["init_" + k] = v
+        sampler = refmain.RandomCubeSampler(data, weight, cf.Compress.coords_mode, cf.Compress.sampler.cube_count,
+                                            copy.deepcopy(cf.Compress.sampler.cube_len), steps, "cpu", True)
+        optim = refmisc.configure_optimizer(nf.module["phi"].parameters(), cf.Compress.optimizer_name_phi, cf.Compress.lr_phi)
+        sched = refmisc.configure_lr_scheduler(optim, cf.Compress.lr_scheduler_phi)
+        thr, _ = refio.normalize_data(np.array(cf.Compress.loss.weight_thres), **cf.Normalize, max=side["max"], min=side["min"])
+        thr = float(thr)
+        losses = []
+        phi = nf.module["phi"]
+        for c, d, w in sampler:           # loop body exactly as main.py:385-400
+            optim.zero_grad()
+            if half:
+                phi.half()
+                d = d.half()
+                yhat = phi.forward(c.half())
+            else:
+                yhat = phi.forward(c)
+            loss = nf.loss_func(d, yhat, w, thr)
+            loss.backward()
+            if half:
+                phi.float()
+            optim.step()
+            sched.step()
+            losses.append(float(loss.item()))
+        dec = refmisc.reconstruct_flattened(list(vol.shape), 10000, nf.sample_nf, device="cpu", half=False,
+                                            coords_mode=cf.Compress.coords_mode)
+        out = refio.invnormalize_data(dec.clone(), side, **cf.Normalize)
+        arrs[tag + "_losses"] = np.array(losses, np.float64)
+        arrs[tag + "_psnr"] = np.array([refmisc.cal_psnr(vol.astype(np.float32), out.astype(np.float32), 65535)], np.float64)
+        print(tag, "loss[0,-1] =", losses[0], losses[-1], "psnr", arrs[tag + "_psnr"])
+    arrs["vol"] = vol
+    arrs["cfg"] = np.array([L_, F_, 20, steps])
+    save("half", **arrs)
+
+
+# ----------------------------------------------------------------------------- 11. windowed RandomCubeSampler
+def g_cube():
+    """RandomCubeSampler with windows smaller than the volume (main.py:38-125): pop_size windows by unfold, cube_count
+    windows per step drawn with torch.randint on the global CPU generator.  Records the window draws, the flat voxel
+    indices every step touches (recovered from the sampled coordinates' positions), and the loss trace."""
+    arrs = {}
+    vol = make_volume((12, 20, 28), seed=49)
+    steps, cube_len, cube_count = 30, [6, 8, 10], 3
+    opt = load_opt()
+    cf = opt.CompressFramework
+    cf.Compress.gpu = False
+    cf.Module.phi.layers = 4
+    cf.Module.phi.w0 = 20
+    cf.Compress.sampler.name = "randomcube"
+    cf.Compress.sampler.cube_len = list(cube_len)
+    cf.Compress.sampler.cube_count = cube_count
+    refmain.reproduc(opt.Reproduc)
+    nf = refmain.NFGR(cf)
+    nf.device = "cpu"
+    weight = refmisc.parse_weight(vol, cf.Compress.loss.weight)
+    data, side = refio.normalize_data(vol, **cf.Normalize)
+    feats, _ = nf.prepare_module(4.0 * SIREN.calc_param_count(3, 1, 32, 4, False))
+    assert feats == 32
+    for k, v in state_arrays(nf.module["phi"]).items():
+        arrs["init_" + k] = v
+    # voxel identity travels through the sampler as a "data" channel: flat index as float32 (exact below 2^24)
+    ident = torch.arange(vol.size, dtype=torch.float32).reshape(vol.shape)
+    s_id = refmain.RandomCubeSampler(ident, weight, cf.Compress.coords_mode, cube_count, list(cube_len), steps, "cpu", True)
+    sampler = refmain.RandomCubeSampler(data, weight, cf.Compress.coords_mode, cube_count, list(cube_len), steps, "cpu", True)
+    arrs["pop_size"] = np.array([sampler.pop_size])
+    optim = refmisc.configure_optimizer(nf.module["phi"].parameters(), cf.Compress.optimizer_name_phi, cf.Compress.lr_phi)
+    sched = refmisc.configure_lr_scheduler(optim, cf.Compress.lr_scheduler_phi)
+    thr, _ = refio.normalize_data(np.array(cf.Compress.loss.weight_thres), **cf.Normalize, max=side["max"], min=side["min"])
+    thr = float(thr)
+    draws, vox, losses = [], [], []
+    orig_randint = torch.randint
+
+    def rec(*a, **k):
+        r = orig_randint(*a, **k)
+        draws.append(r.numpy().copy())
+        return r
+    torch.randint = rec
+    try:
+        for c, d, w in sampler:
+            vox.append(s_id.data_cubes[torch.from_numpy(draws[-1]), :].reshape(-1).numpy().astype(np.int64))
+            optim.zero_grad()
+            yhat = nf.module["phi"].forward(c)
+            loss = nf.loss_func(d, yhat, w, thr)
+            loss.backward()
+            optim.step()
+            sched.step()
+            losses.append(float(loss.item()))
+    finally:
+        torch.randint = orig_randint
+    arrs["vol"] = vol
+    arrs["cfg"] = np.array([4, 32, 20, steps, cube_count] + cube_len)
+    arrs["draws"] = np.stack(draws).astype(np.int64)
+    arrs["voxels"] = np.stack(vox)
+    arrs["losses"] = np.array(losses, np.float64)
+    for k, v in state_arrays(nf.module["phi"]).items():
+        arrs["final_" + k] = v
+    save("cube", **arrs)
+
+
+# ----------------------------------------------------------------------------- 12. adaptive partition: the ILP's inputs
+class _RecVar:
+    def __init__(self, model, name):
+        self.model, self.name, self.idx = model, name, len(model.vars)
+        self.removed = False
+        self.x = 0.0
+
+    def _lin(self):
+        return _RecLin({self.idx: 1.0})
+
+    def __mul__(self, k):
+        return _RecLin({self.idx: float(k)})
+    __rmul__ = __mul__
+
+    def __truediv__(self, k):
+        return _RecLin({self.idx: 1.0 / float(k)})
+
+    def __eq__(self, rhs):
+        return ("==", self._lin(), float(rhs))
+
+    def __le__(self, rhs):
+        return ("<=", self._lin(), float(rhs))
+    __hash__ = object.__hash__
+
+
+class _RecLin:
+    def __init__(self, coef):
+        self.coef = dict(coef)
+
+    def __mul__(self, k):
+        return _RecLin({i: v * float(k) for i, v in self.coef.items()})
+    __rmul__ = __mul__
+
+    def __truediv__(self, k):
+        return _RecLin({i: v / float(k) for i, v in self.coef.items()})
+
+    def __eq__(self, rhs):
+        return ("==", self, float(rhs))
+
+    def __le__(self, rhs):
+        return ("<=", self, float(rhs))
+    __hash__ = object.__hash__
+
+
+class _RecModel:
+    """records what utils/adaptive_blocking.py hands to gurobipy (variables, objective, constraints) and solves the
+    recorded binary program with scipy's HiGHS MILP solver, so that get_active()/draw() of the reference run."""
+
+    def __init__(self):
+        self.vars, self.cons, self.obj = [], [], None
+        self.objVal = None
+
+    def addVar(self, vtype=None, name=""):
+        v = _RecVar(self, name)
+        self.vars.append(v)
+        return v
+
+    def remove(self, v):
+        v.removed = True
+
+    def update(self):
+        pass
+
+    def setObjective(self, expr, sense):
+        self.obj = expr
+
+    def addConstr(self, c):
+        self.cons.append(c)
+
+    def optimize(self):
+        from scipy.optimize import Bounds, LinearConstraint, milp
+        n = len(self.vars)
+        c = np.zeros(n)
+        for i, v in self.obj.coef.items():
+            c[i] = -v
+        A, lo, hi = [], [], []
+        for kind, lin, rhs in self.cons:
+            row = np.zeros(n)
+            for i, v in lin.coef.items():
+                row[i] = v
+            A.append(row)
+            lo.append(rhs if kind == "==" else -np.inf)
+            hi.append(rhs)
+        ub = np.array([0.0 if v.removed else 1.0 for v in self.vars])
+        res = milp(c, constraints=LinearConstraint(np.array(A), lo, hi), integrality=np.ones(n), bounds=Bounds(0, ub))
+        assert res.status == 0, res.message
+        for v, x in zip(self.vars, res.x):
+            v.x = float(round(x))
+        self.objVal = -float(res.fun)
+
+
+def _rec_quicksum(items):
+    tot = {}
+    for it in items:
+        lin = it._lin() if isinstance(it, _RecVar) else it
+        for i, v in lin.coef.items():
+            tot[i] = tot.get(i, 0.0) + v
+    return _RecLin(tot)
+
+
+def g_adaptive():
+    """utils/adaptive_blocking.py:199-423 driven with a RECORDING stand-in for the gurobipy module (the solver is
+    licensed software that is not in the image): the octree, its pruned-node set, every node's cal_feature and the
+    binary program the reference builds (objective coefficients, constraint rows) are the reference's own; only the
+    final argmax is computed by scipy's HiGHS instead of Gurobi.  Any optimal solution has the same objective value."""
+    import utils.adaptive_blocking as rab
+    gp = sys.modules["gurobipy"]
+    gp.Model = _RecModel
+    gp.quicksum = _rec_quicksum
+    gp.GRB = types.SimpleNamespace(BINARY="B", MAXIMIZE=-1)
+    arrs = {}
+    cases = {
+        # tag: (shape, seed, zero-box, var_thr, e_thr, Nb)
+        "a": ((32, 32, 32), 50, None, 0, 0, 8),
+        "b": ((32, 32, 32), 51, (slice(0, 16), slice(0, 16), slice(0, 32)), 0, 0, 12),      # a quarter of the volume is zero -> pruned
+        "c": ((32, 64, 64), 52, (slice(16, 32), slice(32, 64), slice(32, 64)), 0, 0, 20),
+        "d": ((64, 64, 64), 53, (slice(0, 32), slice(0, 64), slice(0, 64)), 0, 0, 64),
+    }
+    for tag, (shape, seed, zbox, vthr, ethr, Nb) in cases.items():
+        vol = make_volume(shape, seed=seed)
+        if zbox is not None:
+            vol[zbox] = 0
+        data = vol                       # (d,h,w,1): cal_feature takes the 4-D branch (3-D FFT), as adaptive_cal_tree passes it
+        import math as _m
+        minl = _m.floor(_m.log(Nb, 8))          # adaptive_cal_tree: utils/adaptive_blocking.py:400-401
+        maxl = minl + 2
+        tree = rab.OctTree(data, maxl, vthr, ethr)
+        tree.solve_optim(Nb, minl)
+        nodes = [[p.level, p.orderz, p.ordery, p.orderx, int(p.prune)] for p in tree.patch_list]
+        feats = [0.0 if p.prune else float(p.feature) for p in tree.patch_list]
+        act = [[p.level, p.orderz, p.ordery, p.orderx] for p in tree.get_active()]
+        m = tree.optim_model
+        coef = np.zeros(len(m.vars))
+        for i, v in m.obj.coef.items():
+            coef[i] = v
+        arrs[tag + "_cfg"] = np.array(list(shape) + [seed, vthr, ethr, Nb, minl, maxl])
+        if zbox is not None:
+            arrs[tag + "_zbox"] = np.array([[s.start, s.stop] for s in zbox])
+        arrs[tag + "_nodes"] = np.array(nodes, np.int64)           # pre-order (tree2list), the order of the variables
+        arrs[tag + "_features"] = np.array(feats, np.float64)
+        arrs[tag + "_objcoef"] = np.array([coef[p.active.idx] for p in tree.patch_list])      # in patch_list order
+        arrs[tag + "_active"] = np.array(act, np.int64)
+        arrs[tag + "_objval"] = np.array([m.objVal])
+        arrs[tag + "_ncons"] = np.array([len(m.cons)])
+        print(tag, "nodes", len(nodes), "pruned", int(sum(n[4] for n in nodes)), "active", len(act), "obj", m.objVal)
+    save("adaptive", **arrs)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["init", "forward", "grads", "optim", "trace", "decode", "budget", "divide", "deblock"]
+    which = sys.argv[1:] or ["init", "forward", "grads", "optim", "trace", "decode", "budget", "divide", "deblock", "half", "cube", "adaptive"]
     for w in which:
         globals()["g_" + w]()

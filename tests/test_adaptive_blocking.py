@@ -1,6 +1,7 @@
 """Adaptive octree partition without Gurobi: the tree-knapsack DP against exhaustive enumeration
-of every feasible selection on small trees, plus cases whose optimum is forced.  (No golden
-exists: the reference's solver needs a Gurobi licence.)"""
+of every feasible selection on small trees, cases whose optimum is forced, and the reference's own
+octree / pruned set / features / binary program (tests/golden/adaptive.npz: utils/adaptive_blocking.py
+run with a recording stand-in for gurobipy, its program solved by scipy's HiGHS)."""
 import itertools
 
 import numpy as np
@@ -87,3 +88,61 @@ def test_pruned_region_is_left_out_and_levels():
     assert len(chunks) <= 20
     assert ab.adaptive_levels(-1, 4 * 1361 * 70.5) == (70, 2, 4)
     assert ab.adaptive_levels(-1, 10.0) == (1, 0, 2)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_octree_program_and_optimum_match_the_reference(golden, tag):
+    """tree order, pruned nodes, cal_feature of every node and the objective coefficients are the reference's;
+    the DP's optimum equals the optimum of the reference's recorded binary program (any optimal solution has it)"""
+    g = golden("adaptive")
+    cfg = [int(v) for v in g[tag + "_cfg"]]
+    shape, (seed, vthr, ethr, Nb, minl, maxl) = tuple(cfg[:3]), cfg[3:]
+    vol = make_volume(shape, seed=seed)
+    if tag + "_zbox" in g:
+        zb = g[tag + "_zbox"]
+        vol[zb[0][0]:zb[0][1], zb[1][0]:zb[1][1], zb[2][0]:zb[2][1]] = 0
+    assert ab.adaptive_levels(Nb, 1e6) == (Nb, minl, maxl)
+    root = ab.build_tree(vol.shape, maxl)
+    ab.prune_and_score(root, vol, vthr, ethr)
+    nodes = list(ab.iter_nodes(root))
+    assert [[n.level, n.oz, n.oy, n.ox, int(n.pruned)] for n in nodes] == g[tag + "_nodes"].tolist()
+    feats = np.array([0.0 if n.pruned else n.feature for n in nodes])
+    assert np.allclose(feats, g[tag + "_features"], rtol=1e-12, atol=0)
+    coef = np.array([0.0 if n.pruned else n.feature / 8.0 ** n.level for n in nodes])
+    assert np.allclose(coef, g[tag + "_objcoef"], rtol=1e-12, atol=0)
+    active, val = ab.solve_tree(root, Nb, minl)
+    ref_val = float(g[tag + "_objval"][0])
+    assert abs(val - ref_val) <= 1e-9 * abs(ref_val), (val, ref_val)
+    # feasible in the reference's program (rows 1-4 of OctTree.solve_optim)
+    assert len(active) <= Nb and all(a.level >= minl and not a.pruned for a in active)
+    act = {id(a) for a in active}
+
+    def check(n, above, chain_pruned):
+        here = above + (1 if id(n) in act else 0)
+        if not n.children:
+            assert (here == 1) if not (chain_pruned or n.pruned) else here <= 1
+        for c in n.children:
+            check(c, here, chain_pruned or n.pruned)
+    check(root, 0, False)
+    ref_active = sorted(map(tuple, g[tag + "_active"].tolist()))
+    mine = sorted((a.level, a.oz, a.oy, a.ox) for a in active)
+    ref_sum = sum(coef[i] for i, n in enumerate(nodes) if (n.level, n.oz, n.oy, n.ox) in set(ref_active))
+    assert abs(ref_sum - ref_val) <= 1e-9 * abs(ref_val)
+    assert mine == ref_active            # no ties in these cases: the optimum is unique
+
+
+def test_quadtree_partition_of_an_rgb_image():
+    """2-D data (h,w,3): quadtree with 4^level weights; covers every non-constant pixel exactly once"""
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, size=(64, 96, 3)).astype(np.uint8)
+    img[:32, :48] = 0
+    chunks, outline = ab.adaptive_chunk(img, 1e6, "adaptive_-1_-1_0_0_12")
+    assert ab.adaptive_levels(12, 1e6, 2) == (12, 1, 3)
+    cover = np.zeros(img.shape[:2], np.int32)
+    for c in chunks:
+        r = parse_chunk_name(c["name"])
+        assert "d" not in r
+        cover[r["h"][0]:r["h"][1] + 1, r["w"][0]:r["w"][1] + 1] += 1
+        assert np.array_equal(c["data"], img[r["h"][0]:r["h"][1] + 1, r["w"][0]:r["w"][1] + 1])
+    assert cover[:32, :48].max() == 0 and cover.max() == 1 and (cover[32:] == 1).all() and (cover[:, 48:] == 1).all()
+    assert 1 <= len(chunks) <= 12 and outline.shape == img.shape

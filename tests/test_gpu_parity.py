@@ -258,6 +258,21 @@ def test_trace_randompoint_golden(golden):
         assert np.max(np.abs(m.net[l][0].weight.data.cpu().numpy() - g["pt_final_w%d" % l])) < 5e-5
 
 
+def test_trace_windowed_cube_golden(golden):
+    """the reference's RandomCubeSampler with 3 windows of 6x8x10 per step on a 12x20x28 volume (main.py:38-125),
+    recorded voxel stream replayed through the fused step: 30-step loss trace and final weights"""
+    g = golden("cube")
+    L = int(g["cfg"][0])
+    m, d, p = make_net(L, int(g["cfg"][1]), float(g["cfg"][2]), ws=[g["init_w%d" % l] for l in range(L)], bs=[g["init_b%d" % l] for l in range(L)])
+    vol = g["vol"]
+    vn, side = O.normalize(vol)
+    thr = float(O.normalize(np.array([65535], np.uint16), vmin=side["min"], vmax=side["max"])[0][0])
+    losses = _fit_gpu(m, int(g["cfg"][3]), vn, vol.shape[:3], g["voxels"], thr)
+    assert np.max(np.abs(losses - g["losses"]) / g["losses"]) < 1e-4
+    for l in range(L):
+        assert np.max(np.abs(m.net[l][0].weight.data.cpu().numpy() - g["final_w%d" % l])) < 5e-5
+
+
 def test_decode_golden(golden):
     g = golden("decode")
     vol = g["vol"]

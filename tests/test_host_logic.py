@@ -152,3 +152,25 @@ def test_configure_optimizer_and_scheduler_mirror():
     assert isinstance(misc.configure_lr_scheduler(o, {"name": "StepLR", "step_size": 3}), torch.optim.lr_scheduler.StepLR)
     with pytest.raises(NotImplementedError):
         misc.configure_lr_scheduler(o, {"name": "Cosine"})
+
+
+def test_windowed_cube_sampler_index_stream_matches_the_reference(golden):
+    """RandomCubeSampler with windows smaller than the volume (main.py:38-125): same window draws (global torch RNG after
+    the net's init draws), same window enumeration, same voxel order inside and across windows"""
+    from brief_pytorch_amd.framework import _CubeIndexStream
+    g = golden("cube")
+    L, F, w0, steps, count = (int(v) for v in g["cfg"][:5])
+    cl = [int(v) for v in g["cfg"][5:]]
+    dims = g["vol"].shape[:3]
+    torch.manual_seed(42)                                   # reproduc(opt.Reproduc), main.py:653-661
+    m = SIREN(features=F, layers=L, w0=w0)                  # prepare_module consumes the generator first
+    for l in range(L):
+        assert np.array_equal(m.net[l][0].weight.data.numpy(), g["init_w%d" % l])
+    st = _CubeIndexStream(dims, cl, count, "cpu")
+    assert st.pop_size == int(g["pop_size"][0]) and st.n == count * int(np.prod(cl))
+    for t in range(steps):
+        assert np.array_equal(st(t + 1).numpy(), g["voxels"][t]), t
+    # an explicit generator keeps the stream away from the global one (tests that must not disturb other draws)
+    gen = torch.Generator().manual_seed(1)
+    a = _CubeIndexStream(dims, cl, count, "cpu", generator=gen)(1)
+    assert a.numel() == st.n and int(a.max()) < int(np.prod(dims))
