@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--preroll", type=int, default=200, help="untimed steps before the counted warm-up (clock ramp)")
+    ap.add_argument("--preroll-seconds", type=float, default=0.5, help="... and at least this long")
     ap.add_argument("--encode-steps", type=int, default=2000, help="total optimizer steps of the end-to-end encode figure / psnr_at_bitrate (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-psnr", action="store_true")
@@ -177,7 +178,7 @@ def main():
     # it a short timed window (the driver's --steps 20 --warmup 5 = 30 ms) measures the ramp, not the kernel
     t_pre = time.perf_counter()
     pre = 0
-    while pre < args.preroll or time.perf_counter() - t_pre < 0.5:
+    while pre < args.preroll or time.perf_counter() - t_pre < args.preroll_seconds:
         fit.step()
         pre += 1
         if pre % 50 == 0:

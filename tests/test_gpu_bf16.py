@@ -219,3 +219,21 @@ def test_singletask_bf16_option(tmp_path):
     cf.Compress.half = True
     with pytest.raises(NotImplementedError):
         NFGR(cf, Log=None)
+
+
+def test_bf16_end_of_fit_against_the_reference_low_precision_band(golden):
+    """The band the low-precision path is held to comes from the reference itself: tests/golden/half.npz holds the
+    reference's fp32 run and its own low-precision mode (Compress.half, main.py:388-399: fp16 forward/backward, no
+    master weights) on the same volume, net, seed and 3000 steps.  The reference loses (f32_psnr - f16_psnr) dB by
+    going to half precision; the bf16 MFMA path with fp32 master weights must lose less than that against the
+    reference's fp32 result, and stay within 1 dB of it."""
+    from tests.test_gpu_parity import _fit_half_golden
+    g, losses, psnr = _fit_half_golden(golden, "bf16")
+    ref32, ref16 = float(g["f32_psnr"][0]), float(g["f16_psnr"][0])
+    print("bf16 end-of-fit PSNR %.3f dB; reference fp32 %.3f dB, reference half (fp16) %.3f dB" % (psnr, ref32, ref16))
+    assert ref32 - ref16 > 1.0                       # the reference's own low-precision cost on this case (3.7 dB)
+    assert psnr > ref16                              # better than the reference's low-precision mode
+    assert abs(psnr - ref32) < 1.0                   # and within 1 dB of the reference's fp32 fit
+    e200 = float(np.max(np.abs(losses[:200] - g["f32_losses"][:200]) / g["f32_losses"][:200]))
+    print("bf16 loss trace vs the reference's fp32 trace through step 200: %.2e" % e200)
+    assert e200 < 2e-2

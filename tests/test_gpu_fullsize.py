@@ -146,7 +146,7 @@ def test_c3_bf16_full_size_step_against_the_oracle_and_properties():
     L, F, dims = 9, 512, (512, 512, 512)
     m, p, tgt, idx, x, y = _full_size_case(L, F, dims, seed=12, precision="bf16")
     loss, yhat = m.train_step(N, tgt, idx=idx, grid=(dims, -1.0, 1.0), want_yhat=True)
-    g16 = m.grads.clone()
+    g16, loss = m.grads.clone(), loss.clone()          # (the returned loss is the module's buffer: later steps overwrite it)
     d = O.make_desc(3, 1, L, F, 20.0)
     for f64 in (False, True):
         lo, go, yo, _ = O.loss_grad(d, p, x, y, f64=f64)
@@ -155,8 +155,9 @@ def test_c3_bf16_full_size_step_against_the_oracle_and_properties():
         gn = float(np.linalg.norm(g16.cpu().numpy().astype(np.float64) - go) / np.linalg.norm(go))
         print("bf16 vs oracle %s: loss rel %.2e, yhat %.2e, gradient L2 %.2e, per-tensor max-abs errors %s" %
               ("f64" if f64 else "f32", abs(loss.item() - lo) / lo, ey, gn, ["%.1e" % e for e in errs]))
-        assert abs(loss.item() - lo) / lo < 2e-4
-        assert ey < 5e-2 and gn < 3e-2 and max(errs) < 8e-2
+        # measured on MI355X: loss 3.7e-7, yhat 8.8e-3 of max|y|, gradient L2 3.4e-3, worst tensor 6.2e-3 of its max-abs
+        assert abs(loss.item() - lo) / lo < 1e-5
+        assert ey < 2e-2 and gn < 1e-2 and max(errs) < 2e-2
     # bit-reproducible
     loss2, _ = m.train_step(N, tgt, idx=idx, grid=(dims, -1.0, 1.0))
     assert torch.equal(g16, m.grads) and loss.item() == loss2.item()
@@ -170,5 +171,5 @@ def test_c3_bf16_full_size_step_against_the_oracle_and_properties():
     comb = (ga * h + gb * (N - h)) / N
     lin = float((comb - g16.double()).norm() / g16.double().norm())
     print("bf16 batch-split linearity: %.2e" % lin)
-    assert lin < 5e-3
+    assert lin < 5e-4                                   # measured 2.8e-5
     assert abs((la * h + lb * (N - h)) / N - loss.item()) / loss.item() < 1e-5

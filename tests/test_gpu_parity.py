@@ -273,6 +273,40 @@ def test_trace_windowed_cube_golden(golden):
         assert np.max(np.abs(m.net[l][0].weight.data.cpu().numpy() - g["final_w%d" % l])) < 5e-5
 
 
+def _fit_half_golden(golden, precision):
+    """the volume, net and schedule of tests/golden/half.npz (5x128 SIREN, 24x32x40 volume, full batch, Adamax) fitted
+    by brief_siren_fit; returns (loss trace, PSNR of the decoded uint16 volume)"""
+    from brief_pytorch_amd.fit import Fitter
+    g = golden("half")
+    L, F, w0, steps = (int(v) for v in g["cfg"])
+    vol = g["vol"]
+    vn, side = O.normalize(vol)
+    m = SIREN(features=F, layers=L, w0=w0, precision=precision)
+    for l in range(L):
+        m.net[l][0].weight.data = torch.from_numpy(g["init_w%d" % l])
+        m.net[l][0].bias.data = torch.from_numpy(g["init_b%d" % l])
+    m.to(DEV)
+    thr = float(O.normalize(np.array([65535], np.uint16), vmin=side["min"], vmax=side["max"])[0][0])
+    tv = torch.from_numpy(vn.reshape(-1, 1)).to(DEV)
+    fit = Fitter(m, tv, vol.shape[:3], sampler="full", optimizer="Adamax", lr=1e-3, thr=thr,
+                 scheduler={"name": "MultiStepLR", "milestones": [50000, 60000, 70000], "gamma": 0.2})
+    losses = fit.run(steps, log=True).cpu().numpy().astype(np.float64)
+    dec = m.decode_grid(vol.shape[:3], out_kind="u16", scale=(0.0, 100.0), vrange=(side["min"], side["max"])).cpu().numpy().reshape(vol.shape)
+    return g, losses, O.psnr(vol, dec, 65535)
+
+
+def test_end_of_fit_3000_steps_golden(golden):
+    """a 3000-step fit of a 128-wide net to its end against the reference's own run (the reference
+    vs itself with another thread count is 2e-6 apart at step 200, 2e-3 at step 3000 and 0.01 dB apart in final PSNR)"""
+    g, losses, psnr = _fit_half_golden(golden, "fp32")
+    ref = g["f32_losses"]
+    e200 = float(np.max(np.abs(losses[:200] - ref[:200]) / ref[:200]))
+    print("3000-step fit: trace error through step 200 %.2e, at the end %.2e; PSNR %.3f dB (reference %.3f dB)" %
+          (e200, abs(losses[-1] - ref[-1]) / ref[-1], psnr, float(g["f32_psnr"][0])))
+    assert e200 < 1e-4
+    assert abs(psnr - float(g["f32_psnr"][0])) < 0.1
+
+
 def test_decode_golden(golden):
     g = golden("decode")
     vol = g["vol"]
