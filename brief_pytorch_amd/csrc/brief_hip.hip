@@ -17,10 +17,10 @@
 // fragment order so each wave-instruction loads one contiguous 1 KiB block (L2 resident).
 //
 //   k_fused<NT,TRAIN>  coords -> layer0 -> hidden layers -> head -> loss -> dgrad chain.
-//                      TRAIN stores Z_l (pre-activations) and D_l (deltas) as [feature][sample]
+//                      TRAIN stores Z_l (phases w z reduced to revolutions) and D_l (deltas) as [feature][sample]
 //                      panels for the weight-gradient GEMM and accumulates the skinny gradients
 //                      (first layer, head) itself.
-//   k_wgrad<NT>        dW_l = D_l * sin(w Z_{l-1})^T, split-K over sample chunks, fp32 slabs.
+//   k_wgrad<NT>        dW_l = D_l * sin(2 pi Z_{l-1})^T, split-K over sample chunks, fp32 slabs.
 //   k_small<NT,HB>     F <= 64 (what BRIEF's YAMLs produce): the whole train step without any HBM stash, z in
 //                      registers, dW accumulated in registers across the persistent tile loop.
 //   k_reduce           deterministic slab/record reduction -> canonical gradient buffer + loss
@@ -86,7 +86,7 @@ struct FusedArgs {
     GridArgs grid;
     int loss_kind;
     float thr, beta, inv_count;
-    float *Z;            // [(L-2)][FP][npad]   pre-activations of layers 0..L-3
+    float *Z;            // [(L-2)][FP][npad]   phases (om z reduced to revolutions) of layers 0..L-3
     float *D;            // [(L-2)][FP][npad]   deltas of layers 1..L-2
     int64_t npad;
     float *rec;          // [gridDim.x*4][BRIEF_REC_FLOATS]
@@ -100,6 +100,8 @@ struct FusedArgs {
     float scale_min, den, span, vmin;   // fused invnormalize
     int stagger_cus;     // workgroups per residency slot (= CU count)
     int stagger;         // s_sleep(127) units of start delay per slot
+    int diag;            // timing diagnostics only (BRIEF_DIAG): bit 0 = stash descriptors with zero records (the range check then
+                         // drops every stash load and store: results are wrong, the instruction stream is unchanged)
 };
 
 // Workgroup barrier for LDS hand-offs only.  __syncthreads() also emits s_waitcnt vmcnt(0), which
@@ -300,6 +302,7 @@ __global__ __launch_bounds__(256, TRAIN ? (NT > 8 ? 1 : BRIEF_TRAIN_WPE) : (NT >
 #ifdef BRIEF_STAMPS
     float st_acc[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     long long st_last = clock64();
+    const long long st_c0 = st_last, st_r0 = wall_clock64();      // shader cycles / 100 MHz reference: the clock the kernel ran at
 #endif
     using K = KCfg<NT>;
     using LD = FusedLds<NT>;
@@ -323,7 +326,7 @@ __global__ __launch_bounds__(256, TRAIN ? (NT > 8 ? 1 : BRIEF_TRAIN_WPE) : (NT >
     const float4 *W0p = reinterpret_cast<const float4 *>(pk + brief_pk_w0(d));
     const __amdgpu_buffer_rsrc_t rs_pk =
         __builtin_amdgcn_make_buffer_rsrc((void *)pk, 0, (int)(brief_pk_count(d) * 4), 0x00020000);
-    const int stash_bytes = (int)((int64_t)K::FP * npad * 4);   // one [FP][npad] panel (host checks < 2^31)
+    const int stash_bytes = (a.diag & 1) ? 0 : (int)((int64_t)K::FP * npad * 4);   // one [FP][npad] panel (host checks < 2^31)
     const int row_bytes = (int)(npad * 4);
 
     // head weights -> LDS once per workgroup (every lane needs all of them in the head dot product)
@@ -463,6 +466,10 @@ __global__ __launch_bounds__(256, TRAIN ? (NT > 8 ? 1 : BRIEF_TRAIN_WPE) : (NT >
             for (int t = 0; t < K::MTW; ++t) {
                 const int mt = wm + K::WM * t;
                 if (K::EXACT || mt < NT) {
+                    // the phase om z reduced to revolutions in [-1/2, 1/2]: what sin and cos are taken of, here and (TRAIN) again
+                    // from the stash by the dgrad chain (cos) and by k_wgrad (sin) without repeating the reduction
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t][r] = brief_revolutions(om * acc[t][r]);
                     if (TRAIN && !last) {
                         const __amdgpu_buffer_rsrc_t rz =
                             __builtin_amdgcn_make_buffer_rsrc((void *)(a.Z + (int64_t)l * K::FP * npad), 0, stash_bytes, 0x00020000);
@@ -475,7 +482,7 @@ __global__ __launch_bounds__(256, TRAIN ? (NT > 8 ? 1 : BRIEF_TRAIN_WPE) : (NT >
                     }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float fr = brief_revolutions(om * acc[t][r]);
+                        const float fr = acc[t][r];
                         hreg[t][r] = BRIEF_SIN_REV(fr);
                         if (TRAIN && last) creg[t][r] = om * BRIEF_COS_REV(fr);
                     }
@@ -652,7 +659,7 @@ __global__ __launch_bounds__(256, TRAIN ? (NT > 8 ? 1 : BRIEF_TRAIN_WPE) : (NT >
                 if (K::EXACT || mt < NT) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        dl[t][r] = acc[t][r] * om * brief_fast_cosf(om * zr[t][r]);
+                        dl[t][r] = acc[t][r] * om * BRIEF_COS_REV(zr[t][r]);      // the stash holds revolutions
                 }
             }
         }
@@ -703,6 +710,8 @@ __global__ __launch_bounds__(256, TRAIN ? (NT > 8 ? 1 : BRIEF_TRAIN_WPE) : (NT >
             rec[BRIEF_REC_LOSS] = lsum;
 #ifdef BRIEF_STAMPS
             for (int i = 0; i < 10; ++i) rec[BRIEF_REC_STAMPS + i] = st_acc[i];
+            rec[BRIEF_REC_STAMPS + 10] = (float)(clock64() - st_c0);
+            rec[BRIEF_REC_STAMPS + 11] = (float)(wall_clock64() - st_r0);
 #endif
         }
     }
@@ -880,9 +889,13 @@ __global__ __launch_bounds__(256, small_wpe(HB)) void k_small(const FusedArgs a)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) bnext[q] = *reinterpret_cast<const float4 *>(bp_ + 32 * wm + 8 * q + 4 * hi);
                 }
+                // keep the phase om z reduced to revolutions: the backward pass takes sin and cos of it again without
+                // repeating the reduction (same bits: the reduction is a function of om z alone)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][r] = brief_revolutions(om * acc[0][r]);
                 zst[l] = acc[0];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) hreg[0][r] = BRIEF_SIN_REV(brief_revolutions(om * acc[0][r]));
+                for (int r = 0; r < 16; ++r) hreg[0][r] = BRIEF_SIN_REV(acc[0][r]);
                 write_image<NT>(Xs, hreg, wm, lane);
                 TILE_BARRIER()
                 STAMP(2)
@@ -990,7 +1003,7 @@ __global__ __launch_bounds__(256, small_wpe(HB)) void k_small(const FusedArgs a)
     if ((layer) == L - 2) {                                                                              \
         const float omt = (layer) == 0 ? d.w0_first : d.w0_hidden;                                       \
         _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                   \
-            dl[0][r] *= omt * BRIEF_COS_REV(brief_revolutions(omt * zst[(layer)][r]));                   \
+            dl[0][r] *= omt * BRIEF_COS_REV(zst[(layer)][r]);                                            \
     }
         // ---- backward through the hidden layers L-2 .. 1: dW_l += delta_l h_{l-1}^T, delta_{l-1} = (W_l^T delta_l) . c_{l-1}
 #pragma unroll
@@ -1001,7 +1014,7 @@ __global__ __launch_bounds__(256, small_wpe(HB)) void k_small(const FusedArgs a)
                 f32x16 cp;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float fr = brief_revolutions(om1 * zst[li - 1][r]);
+                    const float fr = zst[li - 1][r];
                     HTw[ROWMAP(r, hi) * 36 + ln] = BRIEF_SIN_REV(fr);
                     cp[r] = om1 * BRIEF_COS_REV(fr);
                     DTw[ROWMAP(r, hi) * 36 + ln] = dl[0][r];
@@ -1129,7 +1142,7 @@ __global__ __launch_bounds__(256, small_wpe(HB)) void k_small(const FusedArgs a)
 
 // ---------------------------------------------------------------------------------------------
 // (the bf16 kernels are included after the optimizer helpers below)
-// weight-gradient GEMM: dW_l[fo][fi] = sum_n D_l[fo][n] * sin(w Z_{l-1}[fi][n]),  db_l = sum_n D_l
+// weight-gradient GEMM: dW_l[fo][fi] = sum_n D_l[fo][n] * sin(2 pi Z_{l-1}[fi][n]),  db_l = sum_n D_l   (Z: revolutions)
 struct WgradArgs {
     brief_siren_desc d;
     const float *Z;
@@ -1186,7 +1199,6 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
     const int split = bsl % a.nsplit;
     const int64_t nchunks = a.npad / 32;
     const int64_t c0 = nchunks * split / a.nsplit, c1 = nchunks * (split + 1) / a.nsplit;   // c1 > c0 (host: nsplit <= nchunks)
-    const float om = (l - 1) == 0 ? a.d.w0_first : a.d.w0_hidden;
     const float *Dl = a.D + ((int64_t)(l - 1) * FP + qm * QP) * a.npad;     // this quadrant's delta rows
     const float *Zl = a.Z + ((int64_t)(l - 1) * FP + qn * QP) * a.npad;     // ... and z rows
 
@@ -1235,8 +1247,8 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
         const int e = tid + 512 * (i);                                                            \
         if (FULL || e < QP * 8) {                                                                 \
             float4 h;                                                                             \
-            h.x = brief_fast_sinf(om * rb[i].x); h.y = brief_fast_sinf(om * rb[i].y);             \
-            h.z = brief_fast_sinf(om * rb[i].z); h.w = brief_fast_sinf(om * rb[i].w);             \
+            h.x = BRIEF_SIN_REV(rb[i].x); h.y = BRIEF_SIN_REV(rb[i].y);   /* the stash holds revolutions */ \
+            h.z = BRIEF_SIN_REV(rb[i].z); h.w = BRIEF_SIN_REV(rb[i].w);                           \
             *reinterpret_cast<float4 *>(smem + (buf) * 2 * PANEL + PANEL + (e >> 3) * LDSW + (e & 7) * 4) = h; \
         }                                                                                         \
     }
@@ -1474,7 +1486,7 @@ __global__ __launch_bounds__(256) void k_reduce(const ReduceArgs a, int nb_hidde
                 if (d.precision == BRIEF_PREC_BF16) {
                     __bf16 *b16 = reinterpret_cast<__bf16 *>(a.pk + brief_pk16_off(d, l));
                     b16[brief_frag16_index(NT, o, i)] = (__bf16)pv;
-                    b16[(int64_t)FP * FP + brief_frag16_index(NT, i, o)] = (__bf16)pv;
+                    b16[(int64_t)FP * FP + brief_frag16_index(NT, i, o)] = (__bf16)(brief_om_prev(d, l) * pv);
                 }
             } else {
                 blk[2 * (int64_t)FP * FP + (r - (int64_t)F * F)] = pv;        // bias
@@ -1562,7 +1574,8 @@ __global__ void k_repack(const brief_siren_desc d, const float *__restrict__ par
                 const int row = 32 * mt + (lanei & 31);
                 const int col = 32 * kt + 16 * sstep + 8 * (j >> 2) + 4 * (lanei >> 5) + (j & 3);
                 float w = 0.f;
-                if (row < F && col < F) w = bwd ? W[(int64_t)col * F + row] : W[(int64_t)row * F + col];
+                // the backward copy carries om_{l-1}: delta_{l-1} = (om W_l^T delta_l) . cos(om z_{l-1})  (brief_bf16.inc)
+                if (row < F && col < F) w = bwd ? brief_om_prev(d, l) * W[(int64_t)col * F + row] : W[(int64_t)row * F + col];
                 union { __bf16 h; uint16_t u; } cv;
                 cv.h = (__bf16)w;
                 word |= (uint32_t)cv.u << (16 * half);
@@ -1816,6 +1829,7 @@ static int env_int(const char *name, int dflt, int lo, int hi)
 }
 static const int g_wg_per_cu = env_int("BRIEF_WG_PER_CU", BRIEF_TRAIN_WPE, 1, 4);
 static const int g_stagger = env_int("BRIEF_STAGGER", 1, 0, 64);
+static const int g_diag = env_int("BRIEF_DIAG", 0, 0, 255);
 static int fused_grid(const brief_siren_desc &d, int64_t n, bool train)
 {
     (void)train;
@@ -2031,12 +2045,11 @@ static Split16 split16(const brief_siren_desc &d, int64_t n)
     s.g_tail = (int)((npad16(n) - s.n_body) / (32 * ns));          // tiles up to the padded size (see k16)
     return s;
 }
-
 template <bool TRAIN>
 static int launch_k16_split(FusedArgs &fa, hipStream_t st)
 {
-    const Split16 sp = split16(fa.d, fa.n);
     const int64_t np = npad16(fa.n);
+    const Split16 sp = split16(fa.d, fa.n);
     if (sp.g_body > 0) {
         fa.n_begin = 0; fa.n_end = sp.g_tail > 0 ? sp.n_body : np; fa.rec_base = 0;
         if (int rc = launch_k16<TRAIN>(fa, sp.g_body, st, 4)) return rc;
@@ -2122,7 +2135,8 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
         if (!batch->idx && batch->rng_pop > 0) { fa.rng_pop = (uint64_t)batch->rng_pop; fa.rng_seed = batch->rng_seed; fa.rng_step = batch->rng_step; }
         fill_grid(fa.grid, grid);
         fa.loss_kind = loss_kind; fa.thr = thr; fa.beta = beta; fa.inv_count = inv16;
-        fa.npad = np; fa.rec = ws + w16.rec; fa.yhat_out = yhat_out;
+        fa.npad = np; fa.rec = ws + w16.rec; fa.yhat_out = yhat_out; fa.diag = g_diag;
+        fa.stagger_cus = kCUs; fa.stagger = g_stagger;
         fa.S16[0] = ws + w16.h; fa.S16[1] = ws + w16.c; fa.S16[2] = ws + w16.dd; fa.S16[3] = ws + w16.x; fa.S16[4] = ws + w16.g;
         const bool prof16 = g_prof_on && g_prof_n < kProfSlots;
         if (prof16) HIP_TRY(hipEventRecord(g_prof_ev[2 * g_prof_n], st));
@@ -2131,7 +2145,7 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
         Wgrad16Args wa;
         memset(&wa, 0, sizeof(wa));
         const int nsp_s = wgrad16_skinny_splits(*d, batch->n);
-        wa.d = *d; wa.npad = np; wa.nsplit = nsp; wa.nsplit_s = nsp_s; wa.bias_jobs = nt == 16 ? 1 : 0; wa.slabs = ws + w16.slabs;
+        wa.d = *d; wa.npad = np; wa.nsplit = nsp; wa.nsplit_s = nsp_s; wa.bias_jobs = 0; wa.slabs = ws + w16.slabs;   // (bias_jobs: k_wgrad16_big computes db_l itself since round 2)
         wa.H = (const __bf16 *)(ws + w16.h); wa.D = (const __bf16 *)(ws + w16.dd);
         wa.X = (const __bf16 *)(ws + w16.x); wa.G = (const __bf16 *)(ws + w16.g);
         const int nb = nt / 4;
@@ -2139,7 +2153,8 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
             static bool big_attr = false;
             const int lds_big = (int)(sizeof(float) * 4 * W16B_PANEL);
             if (!big_attr) { HIP_TRY(hipFuncSetAttribute((const void *)k_wgrad16_big, hipFuncAttributeMaxDynamicSharedMemorySize, lds_big)); big_attr = true; }
-            hipLaunchKernelGGL(k_wgrad16_big, dim3(hidden * 4 * nsp), dim3(512), lds_big, st, wa);
+            const int groups8 = (hidden * nsp + 7) / 8 * 8;        // (layer, split) groups padded to whole XCD rounds (see the kernel)
+            hipLaunchKernelGGL(k_wgrad16_big, dim3(groups8 * 4), dim3(512), lds_big, st, wa);
         } else if (hidden > 0) {
             hipLaunchKernelGGL(k_wgrad16<false>, dim3(hidden * nb * nb * nsp), dim3(256), sizeof(float) * 4 * W16_PANEL, st, wa);
         }
@@ -2183,7 +2198,7 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
     fa.loss_kind = loss_kind; fa.thr = thr; fa.beta = beta; fa.inv_count = inv_count;
     fa.Z = ws + wl.z; fa.D = ws + wl.dd; fa.npad = brief_npad(nt, batch->n);
     fa.rec = ws + wl.rec; fa.slabs = ws + wl.slabs; fa.yhat_out = yhat_out;
-    fa.stagger_cus = kCUs; fa.stagger = g_stagger;
+    fa.stagger_cus = kCUs; fa.stagger = g_stagger; fa.diag = g_diag;
     const bool prof = g_prof_on && g_prof_n < kProfSlots;
     if (prof) HIP_TRY(hipEventRecord(g_prof_ev[2 * g_prof_n], st));
     if (small) {

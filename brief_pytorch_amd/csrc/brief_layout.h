@@ -96,6 +96,9 @@ BL_HD int64_t brief_frag16_index(int NT, int row, int col)
     return ((((int64_t)mt * NT + kt) * 2 + s) * 64 + 32 * hi + i) * 8 + j;
 }
 
+// w0 of the sine layer below hidden layer l (1..L-2): the factor folded into the bf16 copy of W_l^T
+BL_HD float brief_om_prev(const brief_siren_desc &d, int l) { return l - 1 == 0 ? d.w0_first : d.w0_hidden; }
+
 // --- fused-kernel geometry per NT (how the 4 waves of a workgroup split features x sample tiles)
 BL_HD int brief_wm(int nt) { return nt >= 3 ? 4 : nt; }          // waves along features
 BL_HD int brief_ws(int nt) { return 4 / brief_wm(nt); }          // sample tiles (of 32) per workgroup

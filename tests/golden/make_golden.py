@@ -515,14 +515,14 @@ def g_deblock():
 
 
 # ----------------------------------------------------------------------------- 10. Compress.half (fp16) mode
-def g_half():
+def g_half(modes=(("f32", False), ("f16", True)), out_name="half"):
     """The reference's own low-precision mode (main.py:388-399: module.half() for forward/backward, .float() for the
     optimizer step) against its fp32 mode from the same seed on the same volume: loss traces and end-of-fit PSNR.
     This anchors the band the MI355X low-precision path (bf16 MFMA, fp32 master weights) is held to."""
     arrs = {}
     vol = make_volume((24, 32, 40), seed=44)
     steps, L_, F_ = 3000, 5, 128            # a wide-ish net to the end of a 3000-step fit (SURVEY Appendix F's horizon)
-    for tag, half in (("f32", False), ("f16", True)):
+    for tag, half in modes:
         opt = load_opt()
         cf = opt.CompressFramework
         cf.Compress.gpu = False
@@ -538,7 +538,7 @@ def g_half():
         data, side = refio.normalize_data(vol, **cf.Normalize)
         feats, _ = nf.prepare_module(4.0 * SIREN.calc_param_count(3, 1, F_, L_, False))
         assert feats == F_
-        if tag == "f32":
+        if tag == "f32" and out_name == "half":
             for k, v in state_arrays(nf.module["phi"]).items():
                 arrs["init_" + k] = v
         sampler = refmain.RandomCubeSampler(data, weight, cf.Compress.coords_mode, cf.Compress.sampler.cube_count,
@@ -570,9 +570,17 @@ def g_half():
         arrs[tag + "_losses"] = np.array(losses, np.float64)
         arrs[tag + "_psnr"] = np.array([refmisc.cal_psnr(vol.astype(np.float32), out.astype(np.float32), 65535)], np.float64)
         print(tag, "loss[0,-1] =", losses[0], losses[-1], "psnr", arrs[tag + "_psnr"])
-    arrs["vol"] = vol
+    if out_name == "half":
+        arrs["vol"] = vol
     arrs["cfg"] = np.array([L_, F_, 20, steps])
-    save("half", **arrs)
+    save(out_name, **arrs)
+
+
+def g_half_self():
+    """the reference against ITSELF on the case of half.npz: the same fp32 fit with another thread count (only the
+    reduction order of its GEMMs changes).  Run as  BRIEF_GOLDEN_THREADS=1 python make_golden.py half_self  when
+    half.npz was made with 4 threads: the gap between the two traces is the floor below which parity is meaningless."""
+    g_half(modes=(("f32", False),), out_name="half_self")
 
 
 # ----------------------------------------------------------------------------- 11. windowed RandomCubeSampler

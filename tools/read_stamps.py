@@ -18,6 +18,9 @@ rec_off = 2 * hidden * FP * npad
 nrec = 512 * 4
 rec = m._ws[rec_off:rec_off + nrec * 1056].view(nrec, 1056).cpu().numpy()
 st = rec[:, 1030:1040]
+ck = rec[:, 1040:1042]
+ok = ck[:, 1] > 0
+print('in-kernel clock: %.3f GHz (shader cycles per 100 MHz reference tick, median over waves); kernel lifetime %.1f us' % (float(np.median(ck[ok, 0] / ck[ok, 1])) * 0.1, float(np.median(ck[ok, 1])) / 100.0))
 names = ['inputs+layer0', 'fwd chain', 'barrier after chain', 'fwd epilogue(stash,sincos,image)', 'barrier after image', 'head+loss',
          'head-grad + delta + d0 transposes', 'D store + z prefetch', 'barriers+image before bwd chain', 'bwd chain']
 tot = st.sum(1)

@@ -16,7 +16,7 @@ FP = 256 if F <= 256 else 512
 npad = (100000 + 127) // 128 * 128
 stash = (L - 1) * FP * npad // 2
 rec_off = 3 * stash + 2 * (4 * npad // 2)
-st = m._ws[rec_off + 256 * 8: rec_off + 256 * 8 + 256 * 8 * 10].view(256 * 8, 10).cpu().numpy()
+st = m._ws[rec_off + 2 * 256 * 8: rec_off + 2 * 256 * 8 + 256 * 8 * 10].view(256 * 8, 10).cpu().numpy()
 names = ['inputs+layer0', 'fwd chain', 'barrier after chain', 'fwd epilogue (sin/cos, stash, image)', 'barrier after image', 'head+loss+Wh^T g',
          'bwd epilogue (c load, mult, D stash)', 'bwd barriers + image', 'bwd chain', 'tile-end barrier']
 tot = st.sum(1)
