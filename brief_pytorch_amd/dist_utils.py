@@ -26,22 +26,29 @@ def assign_blocks(costs, world):
     return owner
 
 
-def allreduce_sse(sse, count, device):
-    """sum [sse_0..sse_k, count] over ranks (float64, exact for integer-valued SSE < 2^53)"""
+def allreduce_sum(values, device):
+    """sum a small float64 vector over the ranks (SSE per checkpoint, SSIM sums, slice and voxel counts: exact for the
+    integer-valued entries below 2^53).  RCCL over xGMI on GPUs, gloo (host tensors) in the CPU tests."""
     dist, _, _ = dist_info()
     if dist is not None and dist.get_backend() == "gloo":
         device = "cpu"
-    t = torch.tensor(list(sse) + [float(count)], dtype=torch.float64, device=device)
+    t = torch.tensor(np.asarray(values, np.float64), dtype=torch.float64, device=device)
     if dist is not None:
         dist.all_reduce(t)
-    out = t.cpu().numpy()
+    return t.cpu().numpy()
+
+
+def allreduce_sse(sse, count, device):
+    """sum [sse_0..sse_k, count] over ranks"""
+    out = allreduce_sum(list(sse) + [float(count)], device)
     return out[:-1], float(out[-1])
 
 
-def gather_objects(obj):
-    dist, _, world = dist_info()
+def broadcast_object(obj, src=0):
+    """a small picklable object (block names and byte budgets, a directory name) from rank `src` to every rank"""
+    dist, _, _ = dist_info()
     if dist is None:
-        return [obj]
-    out = [None] * world
-    dist.all_gather_object(out, obj)
-    return out
+        return obj
+    box = [obj]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]

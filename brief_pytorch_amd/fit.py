@@ -31,6 +31,48 @@ def multistep_lr(base_lr, milestones, gamma):
     return lr_at
 
 
+def cyclic_lr(base_lr, max_lr, step_size_up=2000, step_size_down=None, mode="triangular", gamma=1.0, scale_mode=None,
+              cycle_momentum=True, base_momentum=0.8, max_momentum=0.9, **_):
+    """torch.optim.lr_scheduler.CyclicLR as the reference configures it (utils/misc.py:188-189: the YAML keys are passed
+    through): returns (lr_at, beta1_at) for optimizer step t (1-based; the scheduler is stepped after every optimizer
+    step, main.py:400, so step t runs with last_epoch = t - 1).  With an Adam-family optimizer torch cycles beta1
+    inversely to the learning rate when cycle_momentum is left at its default (True)."""
+    import math
+    up = float(step_size_up)
+    down = float(step_size_down) if step_size_down is not None else up
+    total = up + down
+    ratio = up / total
+    if mode not in ("triangular", "triangular2", "exp_range"):
+        raise NotImplementedError("CyclicLR mode %r" % mode)
+    if scale_mode is None:
+        scale_mode = "iterations" if mode == "exp_range" else "cycle"
+
+    def scale_fn(x):
+        if mode == "triangular":
+            return 1.0
+        if mode == "triangular2":
+            return 1.0 / (2.0 ** (x - 1))
+        return gamma ** x
+
+    def factors(t):
+        e = t - 1
+        cycle = math.floor(1 + e / total)
+        x = 1.0 + e / total - cycle
+        sf = x / ratio if x <= ratio else (x - 1) / (ratio - 1)
+        return sf, scale_fn(cycle if scale_mode == "cycle" else e)
+
+    def lr_at(t):
+        sf, sc = factors(t)
+        return base_lr + (max_lr - base_lr) * sf * sc
+
+    def beta1_at(t):
+        if not cycle_momentum:
+            return None
+        sf, sc = factors(t)
+        return max_momentum - (max_momentum - base_momentum) * sf * sc
+    return lr_at, beta1_at
+
+
 class Fitter:
     def __init__(self, module, targets, dims, coords_range=(-1.0, 1.0), weights=None, sampler="randompoint",
                  sample_size=100000, optimizer="Adamax", lr=1e-3, scheduler=None, loss="datal2", thr=0.0, beta=0.01,
@@ -63,8 +105,14 @@ class Fitter:
         elif sch.get("name") == "StepLR":
             ss, gm = int(sch["step_size"]), float(sch.get("gamma", 0.1))
             self.lr_at = lambda t: float(lr) * gm ** ((t - 1) // ss)
+        elif sch.get("name") == "CyclicLR":
+            self.lr_at, self.beta1_at = cyclic_lr(**{k: v for k, v in sch.items() if k != "name"})
+            if optimizer == "SGD":
+                self.beta1_at = lambda t: None      # (torch cycles SGD's momentum; the reference builds SGD without momentum and torch then raises)
         else:
             raise NotImplementedError("lr scheduler %r" % sch.get("name"))
+        if not hasattr(self, "beta1_at"):
+            self.beta1_at = lambda t: None
         self.t = 0
         self._sched_name = sch.get("name") or "none"
         self._milestones = sorted(int(v) for v in sch.get("milestones", [])) if sch.get("name") == "MultiStepLR" else []
@@ -77,8 +125,8 @@ class Fitter:
         job are kept alive by this object until the next call."""
         if self.index_stream is not None:
             raise _lib.BriefError("a replayed index stream needs step(): brief_siren_fit draws its indices in-kernel")
-        if self._sched_name == "StepLR":
-            raise _lib.BriefError("StepLR is applied by step()/run(); brief_fit_job carries MultiStepLR only")
+        if self._sched_name in ("StepLR", "CyclicLR"):
+            raise _lib.BriefError("%s is applied by step()/run(); brief_fit_job carries MultiStepLR only" % self._sched_name)
         m = self.m
         m._require_gpu()
         m.sync_packed()
@@ -106,9 +154,9 @@ class Fitter:
     def run(self, steps, log=False):
         """`steps` optimizer steps in ONE C-ABI call (brief_siren_fit): same results, bit for bit, as calling
         step() that many times.  Returns the device loss of the last step, or the per-step loss tensor if log."""
-        if self._sched_name == "StepLR":
-            # closed-form schedule (lr * gamma^(epoch // step_size)), not the running product brief_siren_fit applies:
-            # keep it exact by stepping from here
+        if self._sched_name in ("StepLR", "CyclicLR"):
+            # closed-form schedules (lr * gamma^(epoch // step_size); the triangular cycle), not the running product
+            # brief_siren_fit applies: keep them exact by stepping from here
             losses = [self.step().clone() for _ in range(int(steps))]
             return torch.cat(losses) if log else self.m._loss
         j, loss_log = self.job(steps, log)
@@ -126,8 +174,10 @@ class Fitter:
                 idx = self.index_stream(t)
             else:
                 rng = (self.pop, self.seed, t)      # drawn inside the fused kernel (== brief_sample_indices(pop, seed, t))
+        b1 = self.beta1_at(t)
         return self.m.fit_step(self.n, self.targets, self.opt, self.s1, self.s2, self.lr_at(t), t, idx=idx, weights=self.weights,
-                               grid=(self.dims, self.range[0], self.range[1]), loss=self.loss_name, thr=self.thr, beta=self.beta, rng=rng)
+                               grid=(self.dims, self.range[0], self.range[1]), loss=self.loss_name, thr=self.thr, beta=self.beta, rng=rng,
+                               betas=(0.9 if b1 is None else b1, 0.999))
 
 
 class MultiFitter:

@@ -23,25 +23,28 @@ from .fit import Fitter
 from .io import get_folder_size, get_type_max, invnormalize_data, minmaxany_range, normalize_data, save_yaml, load_yaml
 from .metrics import cal_ssim, eval_performance, gpu_eval_u16, gpu_ssim_u16, psnr_from_sse
 from .misc import (alloc_param, cal_divide_num, divide_data, merge_divided_data, mip_ops, parse_checkpoints,
-                   parse_chunk_name, parse_weight, preprocess)
+                   parse_chunk_name, parse_weight, preprocess, preprocess_is_identity)
 from .modelsave import CopyDir, load_model, save_model
 from .networks import (ALL_CALC_PHI_FEATURES, ALL_CALC_PHI_PARAM_COUNT, get_nnmodule_param_count, init_phi)
-from .tool import read_img, save_img
+from .tool import create_stack, read_img, save_img, write_slab
 
 
 class MyLogger:
     """utils/Logger.py:10-66 without tensorboard: timestamped run directory, script/ copy dir,
     scalar log (metrics.csv with the reference's scalar names)."""
 
-    def __init__(self, outputs_dir="outputs", project_name="single", stdlog=False, tensorboard=False, time=True, **_):
+    def __init__(self, outputs_dir="outputs", project_name="single", stdlog=False, tensorboard=False, time=True, logdir=None, **_):
+        """logdir: attach to a directory another rank created (a multi-rank job: rank 0 picks the timestamped directory
+        and broadcasts it, see main.py) instead of choosing one"""
         import time as _t
-        name = project_name + (_t.strftime("_%Y_%m%d_%H%M%S") if time else "")
-        logdir = opj(outputs_dir, name)
-        if os.path.exists(logdir) and time:
-            for i in range(10):
-                if not os.path.exists("%s-%d" % (logdir, i)):
-                    logdir = "%s-%d" % (logdir, i)
-                    break
+        if logdir is None:
+            name = project_name + (_t.strftime("_%Y_%m%d_%H%M%S") if time else "")
+            logdir = opj(outputs_dir, name)
+            if os.path.exists(logdir) and time:
+                for i in range(10):
+                    if not os.path.exists("%s-%d" % (logdir, i)):
+                        logdir = "%s-%d" % (logdir, i)
+                        break
         os.makedirs(logdir, exist_ok=True)
         self.logdir = logdir
         self.script_dir = opj(logdir, "script")
@@ -61,7 +64,7 @@ class MyLogger:
         pass
 
 
-from .dist_utils import allreduce_sse, assign_blocks, dist_info as _dist, gather_objects  # noqa: E402
+from .dist_utils import allreduce_sum, assign_blocks, broadcast_object, dist_info as _dist  # noqa: E402
 
 
 class NFGR:
@@ -70,12 +73,16 @@ class NFGR:
         self.module = {}
         self.Log = Log
         self.args = args
-        self.half = opt.Compress.half
-        if self.half:
-            raise NotImplementedError("Compress.half (fp16 autocast) is not available on the fused path; "
-                                      "Compress.precision: bf16 is its MI355X counterpart (bf16 MFMA, fp32 master weights)")
+        self.half = bool(opt.Compress.half)
         # optional key of this build (a reference YAML does not have it): fp32 (default, the parity path) | bf16
         self.precision = str(opt.Compress.get("precision", "fp32"))
+        if self.half:
+            # Compress.half of the reference (main.py:388-399: fp16 forward/backward, the fp16-rounded weights are what
+            # the optimizer updates) maps to the bf16 matrix pipe with fp32 master weights; the budget rule keeps the
+            # reference's 2 bytes per parameter (main.py:217, 242).  Pinned band: tests/golden/half.npz — the reference
+            # loses 3.7 dB by its half mode on that case, this path 1.3 dB.
+            logging.warning("Compress.half: running the hidden GEMMs on the bf16 matrix pipe with fp32 master weights (BRIEF_PREC_BF16)")
+            self.precision = "bf16"
         if opt.Compress.loss.name not in ("datal2", "datasmoothl1"):
             raise NotImplementedError(opt.Compress.loss.name)
         if not opt.Compress.gpu or not torch.cuda.is_available():
@@ -171,6 +178,7 @@ class NFGR:
         logdir = logdir or self.Log.logdir
         if data is None:
             data = read_img(data_path)
+        data = np.asarray(data)
         cube = C_.sampler.cube_len
         cube_vox = cube[0] * cube[1] * cube[2] if data.ndim == 4 else cube[1] * cube[2]
         if C_.sampler.name == "randomcube" and min(data.size, cube_vox) > 80 * 80 * 80:
@@ -179,7 +187,7 @@ class NFGR:
         pre = preprocess(data, C_.preprocess.denoise.level, C_.preprocess.denoise.close, C_.preprocess.clip)
         name, ext = ops(opb(data_path))
         save_img(opj(logdir, name + "_preprocessed" + ext), pre)
-        weight = parse_weight(pre, C_.loss.weight)
+        weight = parse_weight(pre, C_.loss.weight).astype(np.float32, copy=False)     # ('exp_x_v' on integer data is float64)
         norm, sideinfos = normalize_data(pre, **opt.Normalize)
         ideal = self.parse_param_size(data_path)
         feats, theory_size = self.prepare_module(ideal)
@@ -252,20 +260,25 @@ class NFGR:
         # step directories are always kept (the reference's inverted -stepstore flag is not reproduced)
 
     def compress(self, data_path, data=None, logdir=None, evaluate=True):
+        """main.py:322-454.  The loop body runs inside libbrief_hip.so: one brief_siren_fit call covers every step up to
+        the next loss-log or checkpoint boundary (the reference's per-step loss.item() sync, main.py:401, is dropped)."""
         C_, Log = self.opt.Compress, self.Log
         ctx = self.prepare_fit(data_path, data, logdir)
         fit = ctx["fit"]
         max_steps = C_.max_steps
         checkpoints = parse_checkpoints(C_.checkpoints, max_steps)
-        t_fit = 0.0
-        for steps in range(1, max_steps + 1):
+        freq = int(C_.loss_log_freq) if Log is not None else 0
+        stops = sorted(set(checkpoints) | (set(range(freq, max_steps + 1, freq)) if freq > 0 else set()) | {max_steps})
+        t_fit, done = 0.0, 0
+        for stop in stops:
             t0 = time.perf_counter()
-            loss = fit.step()
-            if steps % C_.loss_log_freq == 0 and Log is not None:
-                Log.log_metrics({"loss": loss.item()}, steps)      # the only host sync, at log frequency
+            loss = fit.run(stop - done) if fit.index_stream is None else [fit.step() for _ in range(stop - done)][-1]
+            done = stop
+            if freq > 0 and stop % freq == 0:
+                Log.log_metrics({"loss": loss.item()}, stop)      # the only host sync, at log frequency
             t_fit += time.perf_counter() - t0
-            if steps in checkpoints:
-                self.checkpoint(ctx, steps, loss, evaluate)
+            if stop in checkpoints:
+                self.checkpoint(ctx, stop, loss, evaluate)
         self.fit_seconds = t_fit
         return ctx["results"]
 
@@ -295,28 +308,46 @@ class NFGR:
         raise NotImplementedError(dt)
 
     def compress_divide(self, data_path, opt_full, data=None):
-        """partition -> budget -> independent per-block fits spread over the ranks -> per-block decode
-        on the owning rank -> SSE all-reduce (PSNR) -> rank 0 merges, saves and evaluates."""
+        """main.py:509-651 as one torch.distributed job (one process per GPU):
+          rank 0 partitions the volume and sizes the budgets, the (small) block list is broadcast;
+          every rank fits the blocks it owns (longest-first assignment, co-trained on HIP streams) from a memory-mapped
+          view of the volume and writes their artefacts into the shared steps{k}/compressed tree;
+          the decode of the merged volume is sharded by z: a rank decodes the slices of its slab block by block from the
+          stored artefacts (pruned / dropped regions stay zero, utils/misc.py:432), takes SSE and the per-slice SSIM sums on
+          the GPU against the ORIGINAL data, and writes its slab of the output file;
+          one all-reduce of [SSE_k, SSIM-sum_k, slices, voxels] (RCCL over xGMI) gives PSNR / SSIM.  No volume-sized object
+          ever travels between ranks."""
         dist, rank, world = _dist()
         Log, C_ = self.Log, self.opt.Compress
         logdir = Log.logdir
         if data is None:
-            data = read_img(data_path)
+            data = read_img(data_path, mmap=True)
         assert data.ndim == self.opt.Module.phi.coords_channel + 1, "The data dimension {} is inconsistent with the neural network input {}!".format(data.ndim - 1, self.opt.Module.phi.coords_channel)
         assert data.shape[-1] == self.opt.Module.phi.data_channel, "The number of data channels {} is inconsistent with the output of neural network {}!".format(data.shape[-1], self.opt.Module.phi.data_channel)
         orig_sideinfos = {"data_shape": list(data.shape)}
-        pre = preprocess(data, C_.preprocess.denoise.level, C_.preprocess.denoise.close, C_.preprocess.clip)
+        pp = C_.preprocess
+        identity = preprocess_is_identity(data, pp.denoise.level, pp.denoise.close, pp.clip)
         name, ext = ops(opb(data_path))
+        param_size = self.parse_param_size(data_path)
+        pre = None
+        if rank == 0 or not identity:
+            # (a non-trivial denoise / clip is applied to the whole volume, as the reference does before dividing it)
+            pre = data if identity else preprocess(np.asarray(data), pp.denoise.level, pp.denoise.close, pp.clip)
+        # ---- partition + budget: rank 0 only (octree FFT features, variances), then broadcast names and byte budgets
+        desc = None
         if rank == 0:
             save_img(opj(logdir, name + "_preprocessed" + ext), pre)
-        param_size = self.parse_param_size(data_path)
-        chunks, outline = self.divide(pre, data_path, param_size)
-        if rank == 0:
+            chunks, outline = self.divide(pre, data_path, param_size)
             save_img(opj(logdir, "divide" + ext), outline)
-        orig_sideinfos["chunks_numbers"] = len(chunks)
-        chunks = alloc_param(chunks, param_size, C_.divide.param_alloc, C_.divide.param_size_thres)
+            del outline
+            n_all = len(chunks)
+            chunks = alloc_param(chunks, param_size, C_.divide.param_alloc, C_.divide.param_size_thres)
+            desc = {"n_all": n_all, "chunks": [{k: c[k] for k in ("name", "param_size", "size", "total_size")} for c in chunks]}
+        desc = broadcast_object(desc)
+        orig_sideinfos["chunks_numbers"] = desc["n_all"]
+        chunks = desc["chunks"]
         checkpoints = parse_checkpoints(C_.checkpoints, C_.max_steps)
-        # cost model for the assignment: steps x samples/step x train FLOPs of the block's net
+        # cost model for the assignment: steps x samples/step x parameters of the block's net
         costs = []
         for c in chunks:
             task = copy.deepcopy(self.opt)
@@ -325,12 +356,10 @@ class NFGR:
             ns = min(c["size"], C_.sampler.sample_size) if c["size"] > 80 ** 3 else c["size"]
             costs.append(float(C_.max_steps) * ns * pcount)
         owner = assign_blocks(costs, world)
-        sse = np.zeros(len(checkpoints), np.float64)
-        cnt = 0.0
-        decoded = {k: [] for k in checkpoints}
-        # every block this rank owns is prepared first (nets are initialised in partition order, as a serial
-        # run would), then all of them are trained TOGETHER: brief_multi_fit spreads them over HIP streams so the
-        # launches of narrow nets overlap; the results per block are those of a fit on its own.
+        # every block this rank owns is prepared first (nets are initialised in partition order, as a serial run would),
+        # then all of them are trained TOGETHER: brief_multi_fit spreads them over HIP streams so the launches of narrow
+        # nets overlap; the results per block are those of a fit on its own.
+        src = data if identity else pre
         mine = []
         for i, c in enumerate(chunks):
             if owner[i] != rank:
@@ -338,84 +367,174 @@ class NFGR:
             sub = NFGR(_block_opt(self.opt, c["param_size"]), Log=None, args=self.args)
             sub_dir = opj(logdir, "subexps", c["name"])
             os.makedirs(sub_dir, exist_ok=True)
-            block = np.ascontiguousarray(c["data"])
-            mine.append((c, sub, sub_dir, block, sub.prepare_fit(opj(sub_dir, c["name"] + ext), data=block, logdir=sub_dir)))
-        cotrain = len(mine) > 1 and all(m[4]["fit"].index_stream is None for m in mine) and os.environ.get("BRIEF_COTRAIN", "1") != "0"
+            block = np.ascontiguousarray(_orig_block(src, c))
+            mine.append((c, sub, sub_dir, sub.prepare_fit(opj(sub_dir, c["name"] + ext), data=block, logdir=sub_dir)))
+            del block
+        cotrain = (len(mine) > 1 and all(m[3]["fit"].index_stream is None and m[3]["fit"]._sched_name not in ("StepLR", "CyclicLR") for m in mine)
+                   and os.environ.get("BRIEF_COTRAIN", "1") != "0")
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
         t0 = time.perf_counter()
         if cotrain:
             from .fit import MultiFitter
-            group = MultiFitter([m[4]["fit"] for m in mine])
+            group = MultiFitter([m[3]["fit"] for m in mine])
             done = 0
             for k in checkpoints:
                 losses = group.run(k - done)
                 done = k
-                for (c, sub, sub_dir, block, ctx), loss in zip(mine, losses):
+                for (c, sub, sub_dir, ctx), loss in zip(mine, losses):
                     sub.checkpoint(ctx, k, loss, evaluate=False)
         else:
-            for c, sub, sub_dir, block, ctx in mine:
-                for steps in range(1, C_.max_steps + 1):
-                    loss = ctx["fit"].step()
-                    if steps in checkpoints:
-                        sub.checkpoint(ctx, steps, loss, evaluate=False)
-        torch.cuda.synchronize() if torch.cuda.is_available() else None
+            for c, sub, sub_dir, ctx in mine:
+                done = 0
+                for k in checkpoints:
+                    fit = ctx["fit"]
+                    loss = fit.run(k - done) if fit.index_stream is None else [fit.step() for _ in range(k - done)][-1]
+                    done = k
+                    sub.checkpoint(ctx, k, loss, evaluate=False)
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
         self.fit_seconds = time.perf_counter() - t0
-        for c, sub, sub_dir, block, ctx in mine:
-            for ki, k in enumerate(checkpoints):
-                src = opj(sub_dir, "steps{}".format(k), "compressed")
+        # ---- artefact tree (main.py:585-607)
+        for c, sub, sub_dir, ctx in mine:
+            for k in checkpoints:
+                srcd = opj(sub_dir, "steps{}".format(k), "compressed")
                 mdst = opj(logdir, "steps{}".format(k), "compressed", "module", c["name"])
                 sdst = opj(logdir, "steps{}".format(k), "compressed", "sideinfos", c["name"])
                 os.makedirs(mdst, exist_ok=True)
                 os.makedirs(sdst, exist_ok=True)
-                CopyDir(opj(src, "module"), opj(mdst, "module"))
-                shutil.copy(opj(src, "sideinfos.yaml"), opj(sdst, "sideinfos.yaml"))
-                if C_.decompress:
-                    dec = NFGR.decompress(_wrap(sub.opt), opj(mdst, "module"), opj(sdst, "sideinfos.yaml"), self.device)
-                    d64 = dec.astype(np.int64) - np.ascontiguousarray(_orig_block(data, c)).astype(np.int64)
-                    sse[ki] += float((d64 * d64).sum())
-                    decoded[k].append({"data": dec, "name": c["name"], **parse_chunk_name(c["name"])})
-            cnt += float(block.size)
+                CopyDir(opj(srcd, "module"), opj(mdst, "module"))
+                shutil.copy(opj(srcd, "sideinfos.yaml"), opj(sdst, "sideinfos.yaml"))
+            ctx["fit"] = None
+            ctx["phi"] = None
+        mine = None
+        if rank == 0:
+            for k in checkpoints:
+                save_yaml(orig_sideinfos, opj(logdir, "steps{}".format(k), "compressed", "sideinfos.yaml"))
+        _barrier(dist)
         results = {}
         if C_.decompress:
-            tot_sse, tot_cnt = allreduce_sse(sse, cnt, self.device)   # RCCL over xGMI: the one collective of this path
-            tot = np.concatenate([tot_sse, [tot_cnt]])
-            gathered = gather_objects(decoded)                        # decoded blocks to every rank (rank 0 merges)
-            parts = {k: [x for g in gathered for x in g[k]] for k in checkpoints}
-            if rank == 0:
-                drange = get_type_max(data)
-                for ki, k in enumerate(checkpoints):
-                    sdir = opj(logdir, "steps{}".format(k))
-                    save_yaml(orig_sideinfos, opj(sdir, "compressed", "sideinfos.yaml"))
-                    merged = merge_divided_data(parts[k], list(data.shape))
-                    if self.opt.Decompress.keep_decompressed:
-                        os.makedirs(opj(sdir, "decompressed"), exist_ok=True)
-                        save_img(opj(sdir, "decompressed", name + "_decompressed" + ext), merged)
-                    # PSNR from the all-reduced SSE covers the fitted blocks; dropped/pruned blocks decode as zeros
-                    missing = float(data.size) - tot[-1]
-                    sse_all = tot[ki]
-                    if missing > 0:
-                        d64 = merged.astype(np.int64) - data.astype(np.int64)
-                        sse_all = float((d64 * d64).sum())
-                    perf = {"steps": k, "psnr": psnr_from_sse(sse_all, float(data.size), drange)}
-                    if self.opt.Decompress.mse:
-                        perf["mse"] = sse_all / float(data.size)
-                    if self.opt.Decompress.ssim:
-                        if data.dtype == np.uint16 and data.shape[-1] == 1 and min(data.shape[1:3]) >= 11:
-                            ss, ns = gpu_ssim_u16(torch.from_numpy(np.ascontiguousarray(data)).cuda(), torch.from_numpy(np.ascontiguousarray(merged)).cuda())
-                            perf["ssim"] = ss / ns
-                        else:
-                            perf["ssim"] = cal_ssim(data.astype(np.float32), merged.astype(np.float32), drange)
-                    orig_bytes = os.path.getsize(data_path) if os.path.exists(data_path) else data.nbytes
-                    cdir = opj(sdir, "compressed")
-                    theory = get_folder_size(opj(cdir, "sideinfos")) + sum(c["theory_module_size"] for c in chunks)
-                    Log.log_metrics({"compress_ratio/theory": orig_bytes / theory,
-                                     "compress_ratio/actual": orig_bytes / get_folder_size(cdir)}, k)
-                    Log.log_metrics({m: v for m, v in perf.items() if m != "steps"}, k)
-                    _append_csv(opj(logdir, "performance.csv"), perf)
-                    results[k] = perf
-        if dist is not None:
-            dist.barrier()
+            results = self._evaluate_divide(data, data_path, chunks, checkpoints, name, ext)
+        _barrier(dist)
         if rank == 0 and not (self.args is not None and getattr(self.args, "substore", False)):
             shutil.rmtree(opj(logdir, "subexps"), ignore_errors=True)
+        return results
+
+    def _decode_slab(self, step_dir, chunks, z0, z1, shape, dtype):
+        """slices [z0, z1) of the merged volume decoded from the stored artefacts of `step_dir`: every block that meets the
+        slab is evaluated on its own grid over exactly the z-range of the intersection (a contiguous range of its
+        flattened voxels) and pasted by its inclusive index ranges (main.py:299-320, utils/misc.py:430-445); returns a
+        device tensor in the source dtype.  2-D data: the whole image (z0 = 0, z1 = 1)."""
+        three_d = len(shape) == 4
+        tdt = {"uint8": torch.uint8, "uint16": torch.uint16}.get(np.dtype(dtype).name)
+        fused = tdt is not None and minmaxany_range(self.opt.Normalize.name) is not None
+        out_shape = ([z1 - z0] + list(shape[1:])) if three_d else list(shape)
+        slab = torch.zeros(out_shape, dtype=tdt, device=self.device) if fused else np.zeros(out_shape, dtype=np.float32)
+        lo, hi = _coords_range(self.opt.Compress.coords_mode)
+        for c in chunks:
+            r = parse_chunk_name(c["name"])
+            bz0, bz1 = (r["d"][0], r["d"][1] + 1) if three_d else (0, 1)
+            za, zb = max(bz0, z0), min(bz1, z1)
+            if za >= zb:
+                continue
+            mod = opj(step_dir, "compressed", "module", c["name"], "module")
+            side = load_yaml(opj(step_dir, "compressed", "sideinfos", c["name"], "sideinfos.yaml"))
+            y0, y1, x0, x1 = r["h"][0], r["h"][1] + 1, r["w"][0], r["w"][1] + 1
+            if fused:
+                cf = copy.deepcopy(self.opt)
+                cf.Module.phi.features = side["phi_features"]
+                phi = init_phi({**dict(cf.Module.phi), "precision": str(side.get("phi_precision", self.precision))})
+                load_model(phi, mod, "cpu")
+                phi.to(self.device)
+                dims = list(side["data_shape"])[:-1]
+                plane = int(np.prod(dims[1:])) if three_d else int(np.prod(dims))
+                off, cnt = ((za - bz0) * plane, (zb - za) * plane) if three_d else (0, plane)
+                part = phi.decode_grid(dims, lo, hi, offset=off, count=cnt, out_kind="u8" if tdt == torch.uint8 else "u16",
+                                       scale=minmaxany_range(self.opt.Normalize.name), vrange=(side["min"], side["max"]))
+                if three_d:
+                    slab[za - z0:zb - z0, y0:y1, x0:x1] = part.view(zb - za, y1 - y0, x1 - x0, -1)
+                else:
+                    slab[y0:y1, x0:x1] = part.view(y1 - y0, x1 - x0, -1)
+            else:       # other normalisations / dtypes: the whole block through NFGR.decompress on the host
+                dec = NFGR.decompress(_wrap(self.opt), mod, side, self.device)
+                if three_d:
+                    slab[za - z0:zb - z0, y0:y1, x0:x1] += dec[za - bz0:zb - bz0]
+                else:
+                    slab[y0:y1, x0:x1] += dec
+        if fused:
+            return slab
+        return torch.from_numpy(slab.clip(None, get_type_max(np.zeros(1, dtype))).astype(dtype))
+
+    def _evaluate_divide(self, data, data_path, chunks, checkpoints, name, ext):
+        """decode + metrics of the merged volume, sharded by z over the ranks (the reference decodes every block serially in
+        one process, main.py:613-642)"""
+        dist, rank, world = _dist()
+        Log, logdir = self.Log, self.Log.logdir
+        shape = list(data.shape)
+        three_d = len(shape) == 4
+        nz = shape[0] if three_d else 1
+        z0, z1 = (nz * rank // world, nz * (rank + 1) // world) if three_d else ((0, 1) if rank == 0 else (0, 0))
+        drange = get_type_max(data)
+        gpu_metrics = data.dtype == np.uint16 and three_d and shape[-1] == 1 and min(shape[1:3]) >= 11
+        K = len(checkpoints)
+        acc = np.zeros(2 * K + 2, np.float64)        # [SSE_k..., SSIM-sum_k..., slices, elements]
+        keep = bool(self.opt.Decompress.keep_decompressed)
+        out_paths = {}
+        for k in checkpoints:
+            sdir = opj(logdir, "steps{}".format(k))
+            out_paths[k] = opj(sdir, "decompressed", name + "_decompressed" + ext)
+            if keep and rank == 0:
+                os.makedirs(opj(sdir, "decompressed"), exist_ok=True)
+                if three_d:
+                    create_stack(out_paths[k], shape, data.dtype)
+        _barrier(dist)
+        if z1 > z0:
+            orig = np.ascontiguousarray(data[z0:z1]) if three_d else np.ascontiguousarray(data)
+            orig_t = torch.from_numpy(orig).to(self.device) if gpu_metrics else None
+            for ki, k in enumerate(checkpoints):
+                sdir = opj(logdir, "steps{}".format(k))
+                dec_t = self._decode_slab(sdir, chunks, z0, z1, shape, data.dtype)
+                if gpu_metrics:
+                    sse = torch.zeros(1, dtype=torch.float64, device=self.device)
+                    _lib.check(_lib.lib().brief_sse_u16(_lib.ptr(orig_t), _lib.ptr(dec_t), orig_t.numel(), _lib.ptr(sse), _lib.stream_ptr()))
+                    acc[ki] = sse.item()
+                    if self.opt.Decompress.ssim:
+                        acc[K + ki], _ = gpu_ssim_u16(orig_t, dec_t)
+                    dec = dec_t.cpu().numpy() if keep else None
+                else:
+                    dec = dec_t.cpu().numpy()
+                    d64 = dec.astype(np.int64) - orig.astype(np.int64) if np.issubdtype(data.dtype, np.integer) else dec.astype(np.float64) - orig
+                    acc[ki] = float((d64 * d64).sum())
+                    if self.opt.Decompress.ssim:
+                        if three_d:
+                            acc[K + ki] = sum(cal_ssim(orig[i].astype(np.float32), dec[i].astype(np.float32), drange) for i in range(z1 - z0))
+                        else:
+                            acc[K + ki] = cal_ssim(orig.astype(np.float32), dec.astype(np.float32), drange)
+                if keep:
+                    if three_d:
+                        write_slab(out_paths[k], z0, dec)
+                    else:
+                        save_img(out_paths[k], dec)
+            acc[2 * K] = float(z1 - z0)
+            acc[2 * K + 1] = float(orig.size)
+        tot = allreduce_sum(acc, self.device)         # RCCL over xGMI: the one collective of this path
+        results = {}
+        if rank == 0:
+            for ki, k in enumerate(checkpoints):
+                sdir = opj(logdir, "steps{}".format(k))
+                perf = {"steps": k, "psnr": psnr_from_sse(tot[ki], tot[2 * K + 1], drange)}
+                if self.opt.Decompress.mse:
+                    perf["mse"] = tot[ki] / tot[2 * K + 1]
+                if self.opt.Decompress.ssim:
+                    perf["ssim"] = tot[K + ki] / tot[2 * K]
+                orig_bytes = os.path.getsize(data_path) if os.path.exists(data_path) else data.nbytes
+                cdir = opj(sdir, "compressed")
+                theory = get_folder_size(opj(cdir, "sideinfos")) + sum(c["theory_module_size"] for c in chunks)
+                Log.log_metrics({"compress_ratio/theory": orig_bytes / theory,
+                                 "compress_ratio/actual": orig_bytes / get_folder_size(cdir)}, k)
+                Log.log_metrics({m: v for m, v in perf.items() if m != "steps"}, k)
+                _append_csv(opj(logdir, "performance.csv"), perf)
+                results[k] = perf
         return results
 
 
@@ -447,6 +566,11 @@ def _block_opt(cf, param_size):
     o.Compress.preprocess.denoise.close = False
     o.Compress.decompress = False
     return o
+
+
+def _barrier(dist):
+    if dist is not None:
+        dist.barrier()
 
 
 def _orig_block(data, c):

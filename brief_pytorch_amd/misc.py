@@ -48,8 +48,21 @@ def weights_are_trivial(weight_type_list, data, weight_thres_normalized, normali
     return bool(np.all(w == 1.0))
 
 
+def preprocess_is_identity(data, denoise_level, denoise_close, clip_range):
+    """True when preprocess() would return the data unchanged (the shipped defaults on unsigned data: level 0 only
+    rewrites zeros with zeros, the clip covers the dtype's range)"""
+    lo, hi = range_limit(data, clip_range)
+    unsigned = np.issubdtype(data.dtype, np.unsignedinteger)
+    return bool(unsigned and denoise_level <= 0 and lo <= 0 and hi >= np.iinfo(data.dtype).max)
+
+
 def preprocess(data, denoise_level, denoise_close, clip_range):
-    """utils/misc.py:244-254 (identity at the shipped defaults: level 0 only rewrites zeros, clip [0,65535])"""
+    """utils/misc.py:244-254: threshold-denoise (optionally through a binary opening) and clip.  Unlike the reference
+    this does NOT write into its argument: callers keep evaluating against the untouched original (the reference
+    re-reads the file for that, main.py:433, 624); when nothing would change the input itself is returned."""
+    if preprocess_is_identity(data, denoise_level, denoise_close, clip_range):
+        return data
+    data = np.array(data, copy=True)
     if denoise_close is False:
         data[data <= denoise_level] = 0
     else:

@@ -55,11 +55,18 @@ def main(argv=None):
         # "nccl" is RCCL on ROCm; BRIEF_DIST_BACKEND=gloo rehearses the multi-rank path when ranks share a GPU
         dist.init_process_group(os.environ.get("BRIEF_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo"))
     opt = config.load(args.p)
-    log_opt = dict(opt.Log)
+    rank = int(os.environ.get("RANK", "0"))
     if world > 1:
-        log_opt["time"] = False        # every rank must agree on the run directory
-    Log = MyLogger(**log_opt)
-    if int(os.environ.get("RANK", "0")) == 0:
+        # rank 0 picks the (timestamped) run directory, the others attach to it: a second run never lands in the
+        # directory of an earlier one, and directories are created by one process
+        from brief_pytorch_amd.dist_utils import broadcast_object
+        Log = MyLogger(**dict(opt.Log)) if rank == 0 else None
+        logdir = broadcast_object(Log.logdir if rank == 0 else None)
+        if rank != 0:
+            Log = MyLogger(**{**dict(opt.Log), "logdir": logdir})
+    else:
+        Log = MyLogger(**dict(opt.Log))
+    if rank == 0:
         shutil.copy(args.p, Log.script_dir)
     reproduc(opt.Reproduc)
     cf = opt.CompressFramework

@@ -217,8 +217,7 @@ def test_singletask_bf16_option(tmp_path):
     again = NFGR.decompress(config.to_opt({"CompressFramework": cf}), os.path.join(sdir, "compressed", "module"), dict(side))
     assert np.array_equal(again, read_img(os.path.join(sdir, "decompressed", "v_decompressed.tif")))
     cf.Compress.half = True
-    with pytest.raises(NotImplementedError):
-        NFGR(cf, Log=None)
+    assert NFGR(cf, Log=None).precision == "bf16"           # Compress.half maps to the bf16 path
 
 
 def test_bf16_end_of_fit_against_the_reference_low_precision_band(golden):

@@ -292,3 +292,148 @@ def test_cli_dividetask_two_ranks(tmp_path):
     import csv
     rows = list(csv.DictReader(open(os.path.join(run, "performance.csv"))))
     assert abs(float(rows[-1]["psnr"]) - psnr) < 1e-6 and psnr > 20
+
+
+def _run_divide(tmp_path, vol, divide_type, steps=120, given=60000.0, sub="d", mutate=None, ckpt="none"):
+    path = str(tmp_path / (sub + ".tif"))
+    save_img(path, vol)
+    opt = _opt(tmp_path / sub, steps, ckpt, given)
+    cf = opt.CompressFramework
+    cf.Compress.divide.divide_type = divide_type
+    cf.Compress.divide.param_alloc = "by_size"
+    if mutate is not None:
+        mutate(cf)
+    Log = MyLogger(**opt.Log)
+    torch.manual_seed(42)
+    fw = NFGR(cf, Log=Log)
+    res = fw.compress_divide(path, opt)
+    return fw, Log, res, path
+
+
+def test_dividetask_adaptive_octree_mixed_blocks_and_pruned_region(tmp_path):
+    """BASELINE configs 4 / 5 in small, through the real DivideTask path: divide_type adaptive_* with Nb >= 8 (the octree +
+    tree-knapsack route, main.py:456-507), blocks of different sizes, an all-zero region that is pruned (never fitted) and
+    decodes as zeros (utils/adaptive_blocking.py:341-352, utils/misc.py:432), z-sharded decode from the stored artefacts"""
+    from brief_pytorch_amd.synthetic import make_volume
+    vol = make_volume((32, 64, 64), seed=52)
+    vol[16:32, 32:64, 32:64] = 0                       # the golden case "c" of tests/golden/adaptive.npz
+    fw, Log, res, path = _run_divide(tmp_path, vol, "adaptive_-1_-1_0_0_20", steps=150, given=120000.0)
+    cdir = os.path.join(Log.logdir, "steps150", "compressed")
+    names = sorted(os.listdir(os.path.join(cdir, "module")))
+    sizes = set()
+    cover = np.zeros(vol.shape[:3], np.int32)
+    for n in names:
+        r = misc.parse_chunk_name(n)
+        sizes.add((r["d"][1] - r["d"][0] + 1, r["h"][1] - r["h"][0] + 1, r["w"][1] - r["w"][0] + 1))
+        cover[r["d"][0]:r["d"][1] + 1, r["h"][0]:r["h"][1] + 1, r["w"][0]:r["w"][1] + 1] += 1
+    assert 8 <= len(names) <= 20 and len(sizes) >= 2                   # mixed block sizes
+    assert cover[16:32, 32:64, 32:64].max() == 0 and cover.max() == 1   # the zero region belongs to no block
+    assert (cover.sum() + 16 * 32 * 32) == vol[..., 0].size
+    side = config.load(os.path.join(cdir, "sideinfos.yaml"))
+    assert side["chunks_numbers"] == len(names) and list(side["data_shape"]) == list(vol.shape)
+    merged = read_img(os.path.join(Log.logdir, "steps150", "decompressed", "d_decompressed.tif"))
+    assert (merged[16:32, 32:64, 32:64] == 0).all()
+    d = merged.astype(np.float64) - vol.astype(np.float64)
+    assert abs(-10 * np.log10((d * d).mean() / 65535.0 ** 2) - res[150]["psnr"]) < 1e-6
+    from oracle import oracle as O
+    assert abs(O.ssim(vol.astype(np.float32), merged.astype(np.float32), 65535) - res[150]["ssim"]) < 5e-5
+    again = fw.decompress_divide(os.path.join(cdir, "sideinfos.yaml"), os.path.join(cdir, "module"), os.path.join(cdir, "sideinfos"))
+    assert np.array_equal(again, merged)
+    assert res[150]["psnr"] > 25
+
+
+def test_metrics_are_taken_against_the_original_when_denoise_changes_the_data(tmp_path):
+    """preprocess.denoise.level > 0 zeroes dim voxels before the fit; PSNR / the MIP images compare the decode with the
+    UNTOUCHED file (the reference re-reads it, main.py:433, 624), and the caller's array is not written to"""
+    from brief_pytorch_amd.synthetic import make_volume
+    vol = make_volume((12, 20, 24), seed=8)
+    level = int(np.quantile(vol, 0.3))
+    keep = vol.copy()
+
+    def mut(cf):
+        cf.Compress.preprocess.denoise.level = level
+    fw, Log, res, path = _run_divide(tmp_path, vol, "total_1_2_2", steps=100, given=30000.0, mutate=mut)
+    assert np.array_equal(vol, keep)
+    merged = read_img(os.path.join(Log.logdir, "steps100", "decompressed", "d_decompressed.tif"))
+    d = merged.astype(np.float64) - keep.astype(np.float64)
+    assert abs(-10 * np.log10((d * d).mean() / 65535.0 ** 2) - res[100]["psnr"]) < 1e-6
+    # SingleTask: same rule
+    opt = _opt(tmp_path / "s", 80, "none", 8000.0)
+    opt.CompressFramework.Compress.preprocess.denoise.level = level
+    Log2 = MyLogger(**opt.Log)
+    torch.manual_seed(1)
+    r2 = NFGR(opt.CompressFramework, Log=Log2).compress(path)
+    dec = read_img(os.path.join(Log2.logdir, "steps80", "decompressed", "d_decompressed.tif"))
+    d = dec.astype(np.float64) - keep.astype(np.float64)
+    assert abs(-10 * np.log10((d * d).mean() / 65535.0 ** 2) - r2[80]["psnr"]) < 1e-4
+    pre = read_img(os.path.join(Log2.logdir, "d_preprocessed.tif"))
+    assert (pre[keep <= level] == 0).all() and np.array_equal(pre[keep > level], keep[keep > level])
+
+
+def test_dividetask_steplr_and_exp_weights_and_cycliclr(tmp_path):
+    """StepLR / CyclicLR blocks cannot ride brief_fit_job (MultiStepLR only): the DivideTask falls back to the per-block
+    loop instead of failing; an 'exp_x_v' loss-weight map (float64 out of numpy) reaches the kernel as float32"""
+    from brief_pytorch_amd.synthetic import make_volume
+    vol = make_volume((12, 24, 24), seed=9)
+
+    def mut(cf):
+        cf.Compress.lr_scheduler_phi = config.to_opt({"name": "StepLR", "step_size": 30, "gamma": 0.5})
+        cf.Compress.loss.weight = ["exp_20000_0.5"]
+        cf.Compress.loss.weight_thres = 0
+    fw, Log, res, _ = _run_divide(tmp_path, vol, "total_1_2_2", steps=90, given=30000.0, mutate=mut)
+    assert res[90]["psnr"] > 20
+
+    def mut2(cf):
+        cf.Compress.lr_scheduler_phi = config.to_opt({"name": "CyclicLR", "base_lr": 2e-4, "max_lr": 2e-3, "step_size_up": 20})
+    fw, Log, res2, _ = _run_divide(tmp_path, vol, "total_1_2_2", steps=90, given=30000.0, sub="c", mutate=mut2)
+    assert res2[90]["psnr"] > 20
+    w = misc.parse_weight(vol, ["exp_20000_0.5"])
+    assert w.dtype == np.float64                       # what numpy hands back: the framework must cast
+    from brief_pytorch_amd import _lib
+    from brief_pytorch_amd.fit import Fitter
+    m = SIREN(features=16, layers=3).to("cuda")
+    tv = torch.rand(vol.size, 1, device="cuda")
+    with pytest.raises(_lib.BriefError):
+        Fitter(m, tv, vol.shape[:3], weights=torch.from_numpy(w.reshape(-1, 1)).cuda())
+    with pytest.raises(_lib.BriefError):
+        m.train_step(100, tv.double(), grid=(vol.shape[:3], -1.0, 1.0))
+
+
+def test_init_net_path_warm_start_and_half_option(tmp_path):
+    """param.init_net_path (main.py:349-354: weights only, no optimizer state) and Compress.half (mapped to the bf16
+    matrix pipe with the reference's 2-bytes-per-parameter budget rule, main.py:217, 242)"""
+    from brief_pytorch_amd.synthetic import make_volume
+    vol = make_volume((16, 24, 32), seed=10)
+    path = str(tmp_path / "w.tif")
+    save_img(path, vol)
+    given = 4.0 * SIREN.calc_param_count(3, 1, 24, 4)
+    opt = _opt(tmp_path / "a", 200, "none", given)
+    opt.CompressFramework.Module.phi.layers = 4
+    Log = MyLogger(**opt.Log)
+    torch.manual_seed(42)
+    r1 = NFGR(opt.CompressFramework, Log=Log).compress(path)
+    mod = os.path.join(Log.logdir, "steps200", "compressed", "module")
+    # warm start from those weights: step 0 of the second run starts where the first ended
+    opt2 = _opt(tmp_path / "b", 1, "none", given)
+    opt2.CompressFramework.Module.phi.layers = 4
+    opt2.CompressFramework.Compress.param.init_net_path = mod
+    opt2.CompressFramework.Compress.lr_phi = 0.0
+    Log2 = MyLogger(**opt2.Log)
+    torch.manual_seed(7)                                   # a different seed: the init must come from the files
+    r2 = NFGR(opt2.CompressFramework, Log=Log2).compress(path)
+    assert abs(r2[1]["psnr"] - r1[200]["psnr"]) < 1e-9 and abs(r2[1]["ssim"] - r1[200]["ssim"]) < 1e-12
+    a = read_img(os.path.join(Log.logdir, "steps200", "decompressed", "w_decompressed.tif"))
+    b = read_img(os.path.join(Log2.logdir, "steps1", "decompressed", "w_decompressed.tif"))
+    assert np.array_equal(a, b)
+    # Compress.half: bf16 path, 2 bytes per parameter in the budget -> a wider net for the same bytes
+    opt3 = _opt(tmp_path / "h", 150, "none", given)
+    opt3.CompressFramework.Module.phi.layers = 4
+    opt3.CompressFramework.Compress.half = True
+    Log3 = MyLogger(**opt3.Log)
+    torch.manual_seed(42)
+    fw3 = NFGR(opt3.CompressFramework, Log=Log3)
+    assert fw3.precision == "bf16"
+    r3 = fw3.compress(path)
+    side = config.load(os.path.join(Log3.logdir, "steps150", "compressed", "sideinfos.yaml"))
+    assert side["phi_features"] == SIREN.calc_features(given / 2.0, 3, 1, 4) > 24 and side["phi_precision"] == "bf16"
+    assert r3[150]["psnr"] > 25

@@ -174,3 +174,58 @@ def test_windowed_cube_sampler_index_stream_matches_the_reference(golden):
     gen = torch.Generator().manual_seed(1)
     a = _CubeIndexStream(dims, cl, count, "cpu", generator=gen)(1)
     assert a.numel() == st.n and int(a.max()) < int(np.prod(dims))
+
+
+@pytest.mark.parametrize("kw", [dict(base_lr=1e-4, max_lr=1e-3, step_size_up=7), dict(base_lr=1e-4, max_lr=2e-3, step_size_up=5, step_size_down=9, mode="triangular2"),
+                                dict(base_lr=2e-4, max_lr=1e-3, step_size_up=4, mode="exp_range", gamma=0.97),
+                                dict(base_lr=1e-4, max_lr=1e-3, step_size_up=6, cycle_momentum=False)])
+def test_cyclic_lr_matches_torch(kw):
+    """CyclicLR (utils/misc.py:188-189 passes the YAML keys to torch): lr and, for Adam-family optimizers, beta1 of every
+    optimizer step against torch's own scheduler"""
+    from brief_pytorch_amd.fit import cyclic_lr
+    p = torch.nn.Parameter(torch.zeros(3))
+    opt = torch.optim.Adamax([p], lr=1e-3)
+    sch = torch.optim.lr_scheduler.CyclicLR(opt, **kw)
+    lr_at, b1_at = cyclic_lr(**kw)
+    for t in range(1, 60):
+        assert abs(opt.param_groups[0]["lr"] - lr_at(t)) <= 1e-12 * abs(lr_at(t)), t
+        if kw.get("cycle_momentum", True):
+            assert abs(opt.param_groups[0]["betas"][0] - b1_at(t)) <= 1e-12, t
+        else:
+            assert b1_at(t) is None and opt.param_groups[0]["betas"][0] == 0.9
+        p.grad = torch.ones(3)
+        opt.step()
+        sch.step()
+
+
+def test_multitask_expansion(tmp_path):
+    """MultiTask.py:27-85: PRODUCT / CONCAT expansion of dotted overrides over the Static tree, one YAML per combination"""
+    import importlib.util
+    import yaml
+    spec = importlib.util.spec_from_file_location("MultiTask", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "MultiTask.py"))
+    mt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mt)
+    dyn = [{"PRODUCT": [{"CONCAT": [{"a.x": 1, "a.y": "p"}, {"a.x": 2}]},
+                        {"CONCAT": [{"b.k": "u", "Log.project_name": "U"}, {"b.k": "v", "Log.project_name": "V"}, {"b.k": "w"}]}]},
+           {"a.x": 9}]
+    combos = mt.expand({"CONCAT": dyn})
+    assert len(combos) == 2 * 3 + 1
+    assert combos[0] == [("a.x", 1), ("a.y", "p"), ("b.k", "u"), ("Log.project_name", "U")] and combos[-1] == [("a.x", 9)]
+    sweep = {"Dynamic": dyn, "Static": {"Source": {"gpucost": 1}, "Log": {"project_name": "base", "time": True}, "a": {"x": 0, "z": [1, 2]}, "b": {"k": "none"}}}
+    path = tmp_path / "sweep.yaml"
+    path.write_text(yaml.safe_dump(sweep))
+    tasks, temp_dir = mt.gen_task_list(str(path), "main.py")
+    assert [t[0] for t in tasks] == ["exp_%03d" % i for i in range(7)] and os.path.basename(temp_dir) == "temp_opt_base"
+    t1 = yaml.safe_load(open(tasks[1][2]))
+    assert t1 == {"Log": {"project_name": "V", "time": True}, "a": {"x": 1, "z": [1, 2], "y": "p"}, "b": {"k": "v"}}
+    assert tasks[1][1][-2:] == ["-p", tasks[1][2]]
+    # the shipped sweep file expands and every task is a loadable SingleTask option tree
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tasks, temp_dir = mt.gen_task_list(os.path.join(root, "opt", "MultiTask", "default.yaml"), "main.py")
+    try:
+        assert len(tasks) == 2
+        kinds = sorted(yaml.safe_load(open(t[2]))["CompressFramework"]["Compress"]["divide"]["divide_type"] for t in tasks)
+        assert kinds == ["adaptive_-1_-1_0_0_20", "none"]
+    finally:
+        import shutil
+        shutil.rmtree(temp_dir, ignore_errors=True)
