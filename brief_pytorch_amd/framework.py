@@ -307,8 +307,11 @@ class NFGR:
             return divide_data(data, dt)
         raise NotImplementedError(dt)
 
-    def compress_divide(self, data_path, opt_full, data=None):
-        """main.py:509-651 as one torch.distributed job (one process per GPU):
+    def compress_divide(self, data_path, opt_full, data=None, marks=(), on_mark=None):
+        """marks / on_mark: optional measurement hook (bench.py): the fit pauses at each optimizer-step count in `marks` and
+        calls on_mark(step) — between two marks every block of this rank advances by exactly that many steps.
+
+        main.py:509-651 as one torch.distributed job (one process per GPU):
           rank 0 partitions the volume and sizes the budgets, the (small) block list is broadcast;
           every rank fits the blocks it owns (longest-first assignment, co-trained on HIP streams) from a memory-mapped
           view of the volume and writes their artefacts into the shared steps{k}/compressed tree;
@@ -375,15 +378,24 @@ class NFGR:
         if torch.cuda.is_available():
             torch.cuda.synchronize()
         t0 = time.perf_counter()
-        if cotrain:
+        stops = sorted(set(checkpoints) | {int(m) for m in marks if 0 < int(m) <= C_.max_steps})
+        if cotrain or on_mark is not None:
+            # step-synchronous over the blocks of this rank (co-trained on HIP streams when there are several)
             from .fit import MultiFitter
-            group = MultiFitter([m[3]["fit"] for m in mine])
+            fits = [m[3]["fit"] for m in mine]
+            group = MultiFitter(fits) if cotrain else None
             done = 0
-            for k in checkpoints:
-                losses = group.run(k - done)
+            for k in stops:
+                if group is not None:
+                    losses = group.run(k - done)
+                else:
+                    losses = [f.run(k - done) if f.index_stream is None else [f.step() for _ in range(k - done)][-1] for f in fits]
                 done = k
-                for (c, sub, sub_dir, ctx), loss in zip(mine, losses):
-                    sub.checkpoint(ctx, k, loss, evaluate=False)
+                if k in checkpoints:
+                    for (c, sub, sub_dir, ctx), loss in zip(mine, losses):
+                        sub.checkpoint(ctx, k, loss, evaluate=False)
+                if on_mark is not None and k in marks:
+                    on_mark(k)
         else:
             for c, sub, sub_dir, ctx in mine:
                 done = 0
@@ -489,7 +501,7 @@ class NFGR:
                     create_stack(out_paths[k], shape, data.dtype)
         _barrier(dist)
         if z1 > z0:
-            orig = np.ascontiguousarray(data[z0:z1]) if three_d else np.ascontiguousarray(data)
+            orig = np.array(data[z0:z1] if three_d else data, copy=True)      # this rank's slab of the ORIGINAL data
             orig_t = torch.from_numpy(orig).to(self.device) if gpu_metrics else None
             for ki, k in enumerate(checkpoints):
                 sdir = opj(logdir, "steps{}".format(k))

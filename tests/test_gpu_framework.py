@@ -282,7 +282,9 @@ def test_cli_dividetask_two_ranks(tmp_path):
         open(os.path.join(ROOT, "gpurun_out", "divide2_stderr.log"), "w").write(r.stdout + "\n----\n" + r.stderr)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert "steps 120" in r.stdout and "psnr" in r.stdout
-    run = os.path.join(str(tmp_path / "outputs"), "divide")
+    runs = sorted(os.listdir(str(tmp_path / "outputs")))
+    assert len(runs) == 1 and runs[0].startswith("divide_")       # ONE (timestamped) run directory, chosen by rank 0
+    run = os.path.join(str(tmp_path / "outputs"), runs[0])
     cdir = os.path.join(run, "steps120", "compressed")
     assert len(os.listdir(os.path.join(cdir, "module"))) == 4
     merged = read_img(os.path.join(run, "steps120", "decompressed", "synthetic_16x48x64_decompressed.tif"))
@@ -352,6 +354,7 @@ def test_metrics_are_taken_against_the_original_when_denoise_changes_the_data(tm
 
     def mut(cf):
         cf.Compress.preprocess.denoise.level = level
+        cf.Compress.preprocess.denoise.close = False       # plain threshold (with close = [2,2,2] the opening erases this noise-like mask)
     fw, Log, res, path = _run_divide(tmp_path, vol, "total_1_2_2", steps=100, given=30000.0, mutate=mut)
     assert np.array_equal(vol, keep)
     merged = read_img(os.path.join(Log.logdir, "steps100", "decompressed", "d_decompressed.tif"))
@@ -360,6 +363,7 @@ def test_metrics_are_taken_against_the_original_when_denoise_changes_the_data(tm
     # SingleTask: same rule
     opt = _opt(tmp_path / "s", 80, "none", 8000.0)
     opt.CompressFramework.Compress.preprocess.denoise.level = level
+    opt.CompressFramework.Compress.preprocess.denoise.close = False
     Log2 = MyLogger(**opt.Log)
     torch.manual_seed(1)
     r2 = NFGR(opt.CompressFramework, Log=Log2).compress(path)
@@ -367,7 +371,7 @@ def test_metrics_are_taken_against_the_original_when_denoise_changes_the_data(tm
     d = dec.astype(np.float64) - keep.astype(np.float64)
     assert abs(-10 * np.log10((d * d).mean() / 65535.0 ** 2) - r2[80]["psnr"]) < 1e-4
     pre = read_img(os.path.join(Log2.logdir, "d_preprocessed.tif"))
-    assert (pre[keep <= level] == 0).all() and np.array_equal(pre[keep > level], keep[keep > level])
+    assert (pre[keep <= level] == 0).all() and np.array_equal(pre[keep > level], keep[keep > level]) and (pre == 0).mean() > 0.25
 
 
 def test_dividetask_steplr_and_exp_weights_and_cycliclr(tmp_path):
