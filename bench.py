@@ -8,9 +8,10 @@ Workload (BASELINE.json metric: "voxels/sec encode (512^3 vol, 4x256 SIREN)"):
   N=1  SingleTask: synthetic 512^3 uint16 volume, SIREN layers=5 features=256 ("4x256") w0=20,
        randompoint sampler sample_size=100000 (main.py:324-334: volumes > 80^3 use randompoint),
        datal2 loss, Adamax lr 1e-3 + MultiStepLR — the shipped default.yaml settings.
-  N>1  DivideTask: every rank fits its own 512^3 block of a (N x 512^3) volume with its own 4x256
-       net (independent units, main.py:547-575) — weak scaling, no collective on the data path;
-       RCCL only for the barrier/max-time and the final SSE (PSNR) all-reduce.
+  N>1  DivideTask through the product path: NFGR.compress_divide on a (N*512, 512, 512) volume cut into N blocks of
+       512^3 (divide_type total_N_1_1), one block and one 4x256 net per rank (independent units, main.py:547-575) —
+       weak scaling, no collective on the data path; RCCL only for the barriers / max-time and the one
+       [SSE, SSIM-sum, slices, voxels] all-reduce of the z-sharded evaluation.
 A step = one pass of the hot path over one batch: sample 100000 voxels -> fused forward/loss/
 backward -> optimizer update.  value = sampled voxels fitted per second over all ranks, with
 the volume resident in HBM when the timed region starts.
@@ -119,6 +120,72 @@ def torch_cpu_baseline(x, y, p, seconds_budget=10.0):
             "sample": "%d step(s) after 1 warm-up, torch %s CPU autograd" % (steps, torch.__version__)}
 
 
+def divide_bench(args, dist, rank, world, dev, red_dev):
+    """N > 1: the timed steps run INSIDE NFGR.compress_divide (brief_pytorch_amd/framework.py): rank 0 partitions and
+    broadcasts, every rank fits the block it owns from a memory map of the shared volume file, the evaluation is sharded
+    by z.  The fit pauses at two step marks (after pre-roll + warm-up, and K steps later) where this function brackets the
+    timed region with barrier + synchronize."""
+    import shutil
+    import tempfile
+    from brief_pytorch_amd import config
+    from brief_pytorch_amd.dist_utils import broadcast_object
+    from brief_pytorch_amd.framework import NFGR, MyLogger
+    from brief_pytorch_amd.tool import create_stack, write_slab
+    L = _lib.lib()
+    work = broadcast_object(tempfile.mkdtemp(prefix="brief_bench_") if rank == 0 else None)
+    path = os.path.join(work, "volume.npy")
+    shape = (world * BLOCK[0], BLOCK[1], BLOCK[2], 1)
+    if rank == 0:
+        create_stack(path, shape, np.uint16)
+    dist.barrier()
+    blk = make_volume_torch(BLOCK, seed=42 + rank, device=dev)
+    write_slab(path, rank * BLOCK[0], blk.cpu().numpy())           # every rank writes its own block of the shared file
+    del blk
+    torch.cuda.empty_cache()
+    dist.barrier()
+    opt = config.load(os.path.join(ROOT, "opt", "DivideTask", "default.yaml"))
+    cf = opt.CompressFramework
+    pre = args.preroll
+    total_steps = pre + args.warmup + args.steps
+    pcount = SIREN.calc_param_count(3, 1, FEATURES, LAYERS)
+    cf.Compress.divide.divide_type = "total_%d_1_1" % world
+    cf.Compress.divide.param_alloc = "by_size"
+    cf.Compress.param.filesize_ratio, cf.Compress.param.given_size = 0, 4.0 * pcount * world
+    cf.Compress.max_steps, cf.Compress.checkpoints = total_steps, "none"
+    cf.Compress.sampler.name, cf.Compress.sampler.sample_size = "randompoint", SAMPLE
+    cf.Compress.loss_log_freq = 10 ** 9
+    cf.Compress.decompress = not args.no_psnr
+    cf.Module.phi.layers, cf.Module.phi.w0 = LAYERS, W0
+    cf.Compress.precision = args.precision
+    cf["_seed"] = 42
+    cf.Decompress.keep_decompressed, cf.Decompress.mip, cf.Decompress.ssim = False, False, True
+    Log = MyLogger(outputs_dir=work, project_name="run", time=False, logdir=os.path.join(work, "run"))
+    torch.manual_seed(42)
+    fw = NFGR(cf, Log=Log)
+    marks = [pre + args.warmup, total_steps]
+    stamp = {}
+
+    def on_mark(k):
+        dist.barrier()
+        torch.cuda.synchronize()
+        stamp[k] = time.perf_counter()
+        if k == marks[0]:
+            _lib.check(L.brief_profile_enable(1))
+    res = fw.compress_divide(path, opt, marks=marks, on_mark=on_mark)
+    elapsed = stamp[marks[1]] - stamp[marks[0]]
+    tot_ms, launches = C.c_double(0), C.c_int64(0)
+    _lib.check(L.brief_profile_fused(C.byref(tot_ms), C.byref(launches)))
+    _lib.check(L.brief_profile_enable(0))
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed = float(tt.item())
+    perf = res.get(total_steps, {}) if rank == 0 else {}
+    dist.barrier()
+    if rank == 0:
+        shutil.rmtree(work, ignore_errors=True)
+    return elapsed, tot_ms.value / max(launches.value, 1), perf, pcount
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -156,6 +223,36 @@ def main():
     global LAYERS, FEATURES
     if args.config == "c3":
         LAYERS, FEATURES = 9, 512
+
+    if world > 1:
+        elapsed, fused_ms, perf, pcount = divide_bench(args, dist, rank, world, dev, red_dev)
+        if rank == 0:
+            train_f, fused_f, _ = flops_per_sample(LAYERS, FEATURES)
+            peak = PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
+            ms_step = elapsed * 1e3 / args.steps
+            achieved = fused_f * SAMPLE / (fused_ms * 1e-3) / 1e12
+            out = {
+                "metric": "encode_voxels_per_sec", "value": SAMPLE * args.steps * world / elapsed, "unit": "voxels/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
+                "config": {"workload": "DivideTask (NFGR.compress_divide) on a synthetic uint16 volume of %d x 512^3 blocks (total_%d_1_1), one block and "
+                                       "one SIREN %dx%d (layers=%d, features=%d, w0=20) per rank, randompoint sample_size=100000, datal2, Adamax lr=1e-3"
+                                       % (world, world, LAYERS - 1, FEATURES, LAYERS, FEATURES),
+                           "volume": [world * BLOCK[0], BLOCK[1], BLOCK[2]], "layers": LAYERS, "features": FEATURES, "sample_size": SAMPLE,
+                           "params": pcount, "bits_per_voxel": 32.0 * pcount / float(np.prod(BLOCK))},
+                "roofline": {"bound": "mfma", "kernel": ("k_fused<%d,true>" if args.precision == "fp32" else "k16<%d,true,1>") % (FEATURES // 32)
+                             + " (forward+loss+dgrad), rank 0", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                             "traffic": None, "traffic_source": None, "kernel_ms": fused_ms, "flop_per_launch": fused_f * SAMPLE,
+                             "step_tflops": train_f * SAMPLE / (ms_step * 1e-3) / 1e12, "step_frac": train_f * SAMPLE / (ms_step * 1e-3) / 1e12 / peak},
+                "preroll_steps": args.preroll,
+                "psnr_at_bitrate": {"steps": args.preroll + args.warmup + args.steps, "bits_per_voxel": 32.0 * pcount / float(np.prod(BLOCK)),
+                                    "psnr_db": perf.get("psnr"), "ssim": perf.get("ssim"),
+                                    "note": "merged volume, z-sharded decode, [SSE, SSIM-sum, slices, voxels] all-reduced over the ranks"},
+            }
+            print(json.dumps(out), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
 
     # ---- data: this rank's block, generated and normalised on the device (utils/io.py:65-80 op order)
     vol = make_volume_torch(BLOCK, seed=42 + rank, device=dev)
