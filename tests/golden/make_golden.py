@@ -484,33 +484,43 @@ def g_deblock():
                 names.append("d_%d_%d-h_%d_%d-w_%d_%d" % (z1, z2, y1, y2, x1, x2))
                 img[z1:z2 + 1, y1:y2 + 1, x1:x2 + 1] = base[z1:z2 + 1, y1:y2 + 1, x1:x2 + 1] + rng.integers(-150, 150)
     img = np.clip(img, 0, 65535).astype(np.uint16)[..., None]
-    out = img.copy()
-    lines = []
-    for block_info in names:                       # deblock.py:109-130 (3-D branch), explicit order
-        dd, hh, ww = block_info.split('-')
-        z1, z2 = (int(v) for v in dd.split('_')[1:])
-        x1, x2 = (int(v) for v in ww.split('_')[1:])
-        y1, y2 = (int(v) for v in hh.split('_')[1:])
-        l_flag = 1 if [z1, x1, y1, x1, y2] in lines else 0
-        r_flag = 1 if [z1, x2, y1, x2, y2] in lines else 0
-        d_flag = 1 if [z1, x1, y1, x2, y1] in lines else 0
-        u_flag = 1 if [z1, x1, y2, x2, y2] in lines else 0
-        for i in range(z1, z2 + 1):
-            if l_flag == 0:
-                lines.append([i, x1, y1, x1, y2])
-            if r_flag == 0:
-                lines.append([i, x2, y1, x2, y2])
-            if d_flag == 0:
-                lines.append([i, x1, y1, x2, y1])
-            if u_flag == 0:
-                lines.append([i, x1, y2, x2, y2])
-    for k in range(out.shape[-1]):
-        for p in lines:
-            out[p[0], :, :, k] = rd.filter2d(p[1:], out[p[0], :, :, k], 51, 2000, 65535)
+    # drive the reference's own main() (deblock.py:79-130) on a scratch step directory: block names come from the directory
+    # listing (sorted here: os.listdir order is file-system dependent and the order of the lines is part of the result), the
+    # image I/O is replaced by in-memory arrays, filter2d is wrapped to record the boundary lines in processing order
+    import tempfile
+    step = tempfile.mkdtemp(prefix="brief_deblock_")
+    os.makedirs(os.path.join(step, "decompressed"))
+    open(os.path.join(step, "decompressed", "vol_decompressed.tif"), "wb").close()
+    for n in names:
+        os.makedirs(os.path.join(step, "compressed", "module", n))
+    state = {}
+    real_listdir, real_filter = os.listdir, rd.filter2d
+
+    def run(index_a, index_b, thres):
+        work = img.copy()
+        lines, got = [], {}
+        base = work.__array_interface__["data"][0]
+
+        def rec_filter(pt, slice_img, *a):
+            z = (slice_img.__array_interface__["data"][0] - base) // (work.shape[1] * work.shape[2] * work.shape[3] * work.itemsize)
+            lines.append([int(z)] + [int(v) for v in pt])
+            return real_filter(pt, slice_img, *a)
+        rd.read_img = lambda path: work
+        rd.save_img = lambda path, arr: got.setdefault("out", np.array(arr, copy=True))
+        rd.filter2d = rec_filter
+        os.listdir = lambda d: sorted(real_listdir(d))
+        try:
+            rd.main(step, index_a, index_b, thres)
+        finally:
+            os.listdir, rd.filter2d = real_listdir, real_filter
+        return got["out"], lines
+    out, lines = run(51, 2000, 65535)
     # a second run with a brightness threshold that disables part of the volume and a tighter beta
-    out2 = img.copy()
-    for p in lines:
-        out2[p[0], :, :, 0] = rd.filter2d(p[1:], out2[p[0], :, :, 0], 48, 700, 20050)
+    out2, lines2 = run(48, 700, 20050)
+    assert lines2 == lines
+    names = sorted(names)
+    import shutil
+    shutil.rmtree(step, ignore_errors=True)
     save("deblock", img=img, names=np.array(names), lines=np.array(lines), out=out, out2=out2)
 
 
