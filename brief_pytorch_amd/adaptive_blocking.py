@@ -32,6 +32,7 @@ import numpy as np
 from .misc import cal_feature, chunk_name, rgb2gray
 
 NEG = -1.0e300
+GPU_FEATURE_VOXELS = 1 << 24     # volumes from 256^3 up take their octree statistics / FFT features on the GPU when there is one
 
 
 class Node:
@@ -86,10 +87,40 @@ def _feature2d(gray):
     return int(f.max()) / int(f.sum())
 
 
-def prune_and_score(root, data, var_thr=0.0, e_thr=0.0, feature_fn=None, dim=3):
-    """OctTree.prune (:341-352) then get_feature (:289-292)"""
+def _gpu_stats(device):
+    """(variance/mean, feature) of a block evaluated on the GPU in float64 — the same formulas as the numpy path (population
+    variance; max|FFT| / sum|FFT| with both truncated to int).  At BASELINE config 4's size the reference's host version
+    copies and transforms the 1024^3 root and every descendant (O(levels x volume) of complex128 numpy FFTs: minutes and tens
+    of GiB); rocFFT does the four levels in seconds."""
+    import torch
+
+    def to_dev(blk):
+        a = np.ascontiguousarray(blk)
+        if a.dtype == np.uint16:         # (moved as int16 bits, widened on the device: no float64 copy on the host)
+            return (torch.from_numpy(a.view(np.int16)).to(device).to(torch.int32) & 0xFFFF).double()
+        return torch.from_numpy(a).to(device).double()
+
+    def var_mean(blk):
+        t = to_dev(blk)
+        m = t.mean()
+        return float(((t - m) ** 2).mean().item()), float(m.item())
+
+    def feature(blk):
+        t = to_dev(blk)
+        dims = (0, 1, 2) if t.ndim == 4 else (0, 1)
+        f = torch.fft.fftn(t, dim=dims).abs()
+        return int(f.max().item()) / int(f.sum().item())
+    return var_mean, feature
+
+
+def prune_and_score(root, data, var_thr=0.0, e_thr=0.0, feature_fn=None, dim=3, device=None):
+    """OctTree.prune (:341-352) then get_feature (:289-292).  device: a torch device evaluates the block statistics and
+    FFT features there (large volumes); None = numpy, the reference's arithmetic (what the goldens pin)."""
     if feature_fn is None:
         feature_fn = cal_feature if dim == 3 else _feature2d
+    var_mean = None
+    if device is not None:
+        var_mean, feature_fn = _gpu_stats(device)
 
     def mark(n):
         n.pruned = True
@@ -99,8 +130,12 @@ def prune_and_score(root, data, var_thr=0.0, e_thr=0.0, feature_fn=None, dim=3):
         if n.pruned:
             continue
         blk = _block(data, n, dim)
-        m = blk.mean()
-        if ((blk - m) ** 2).mean() <= var_thr and abs(m) <= e_thr:
+        if var_mean is not None:
+            v, m = var_mean(blk)
+        else:
+            m = blk.mean()
+            v = ((blk - m) ** 2).mean()
+        if v <= var_thr and abs(m) <= e_thr:
             mark(n)
     for n in iter_nodes(root):
         if not n.pruned:
@@ -218,7 +253,12 @@ def adaptive_chunk(data, param_size, divide_type):
         raise NotImplementedError("adaptive partition needs (d,h,w,c) or (h,w,c) data")
     Nb, minl, maxl = adaptive_levels(Nb, param_size, dim)
     root = build_tree(tree_data.shape, maxl, dim)
-    prune_and_score(root, tree_data, var_thr, e_thr, dim=dim)
+    device = None
+    if tree_data.size >= GPU_FEATURE_VOXELS:
+        import torch
+        if torch.cuda.is_available():
+            device = "cuda"
+    prune_and_score(root, tree_data, var_thr, e_thr, dim=dim, device=device)
     active, _ = solve_tree(root, Nb, minl, dim)
     outline = data.copy()
     chunks = []

@@ -173,3 +173,26 @@ def test_c3_bf16_full_size_step_against_the_oracle_and_properties():
     print("bf16 batch-split linearity: %.2e" % lin)
     assert lin < 5e-4                                   # measured 2.8e-5
     assert abs((la * h + lb * (N - h)) / N - loss.item()) / loss.item() < 1e-5
+
+
+def test_c4_shaped_dividetask_through_compress_divide():
+    """BASELINE config 4's shape through the product path, at an eighth of its size per edge-doubling (512^3 volume -> eight
+    256^3 octants; the full 1024^3 run of the same script is recorded in profiles/r02_c4_at_size.json): memory-mapped .npy volume,
+    adaptive octree with its block statistics and FFT features on the GPU, eight 4x256 nets co-trained on HIP streams,
+    artefact tree, evaluation of the merged volume, output file written slab-wise."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("c4_at_size", os.path.join(root, "tools", "c4_at_size.py"))
+    mod = importlib.util.module_from_spec(spec)
+    cwd = os.getcwd()
+    os.chdir(root)
+    try:
+        spec.loader.exec_module(mod)
+        out = mod.run(steps=60, E=512, keep_json=False)
+    finally:
+        os.chdir(cwd)
+    assert out["blocks"] == sorted("d_%d_%d-h_%d_%d-w_%d_%d" % (z, z + 255, y, y + 255, x, x + 255) for z in (0, 256) for y in (0, 256) for x in (0, 256))
+    assert out["decoded_shape"] == [512, 512, 512, 1]
+    assert out["perf"]["psnr"] > 24 and 0.5 < out["perf"]["ssim"] <= 1.0
+    assert out["fit_voxels_per_s"] > 2e7
