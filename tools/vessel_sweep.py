@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--ratios", type=float, nargs="+", default=[512, 256, 128, 64])
     ap.add_argument("--shape", type=str, default="64x512x512")
     ap.add_argument("--precision", type=str, default="fp32")
+    ap.add_argument("--divide", type=str, default="", help="override Compress.divide.divide_type (e.g. adaptive_-1_-1_0_0_20: octree + tree knapsack, mixed block sizes)")
+    ap.add_argument("--alloc", type=str, default="", help="override Compress.divide.param_alloc (equal | by_size | by_var | by_d | by_dv)")
     ap.add_argument("--out", type=str, default="")
     ap.add_argument("--workdir", type=str, default="/tmp/vessel_sweep")
     a = ap.parse_args()
@@ -45,6 +47,10 @@ def main():
         cf.Compress.checkpoints = "none"
         cf.Compress.param.filesize_ratio = ratio
         cf.Compress.precision = a.precision
+        if a.divide:
+            cf.Compress.divide.divide_type = a.divide
+        if a.alloc:
+            cf.Compress.divide.param_alloc = a.alloc
         cf.Decompress.mip = False
         cf.Decompress.keep_decompressed = False
         opt.Log.outputs_dir = os.path.join(a.workdir, "outputs")
@@ -58,7 +64,12 @@ def main():
         names = sorted(os.listdir(os.path.join(cdir, "sideinfos")))
         feats = [config.load(os.path.join(cdir, "sideinfos", n, "sideinfos.yaml"))["phi_features"] for n in names]
         nbytes = sum(os.path.getsize(os.path.join(dp, f)) for n in names for dp, _, fs in os.walk(os.path.join(cdir, "module", n)) for f in fs)
-        row = "| %g | %d | %s | %.4f | %d | %.2f | %.2f | %.4f |" % (ratio, len(names), ",".join(str(f) for f in feats), 8.0 * nbytes / vol.size,
+        from collections import Counter
+        from brief_pytorch_amd.misc import parse_chunk_name
+        shapes = Counter("x".join(str(r[k][1] - r[k][0] + 1) for k in "dhw") for r in map(parse_chunk_name, names))
+        print("   block shapes:", dict(shapes), flush=True)
+        feat_txt = ",".join(str(f) for f in feats) if len(feats) <= 8 else "%d..%d (%s)" % (min(feats), max(feats), ", ".join("%d x %s" % (c, s_) for s_, c in sorted(shapes.items())))
+        row = "| %g | %d | %s | %.4f | %d | %.2f | %.2f | %.4f |" % (ratio, len(names), feat_txt, 8.0 * nbytes / vol.size,
                                                                    a.steps, fw.fit_seconds, res["psnr"], res.get("ssim", float("nan")))
         print(row, flush=True)
         lines.append(row)
