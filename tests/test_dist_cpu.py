@@ -66,3 +66,63 @@ def test_two_rank_sse_allreduce():
     for rank, tot, n, full, size, own_cnt in res:
         assert tot == full and n == size and 0 < own_cnt < size
         assert abs(psnr_from_sse(tot, n, 65535) - psnr_from_sse(full, size, 65535)) == 0
+
+
+def _worker_eval(rank, world, port, q):
+    """the collective pattern of NFGR._evaluate_divide without a GPU: rank 0 owns the partition and broadcasts the block
+    list; every rank scores ITS z-slab of the merged volume; one all-reduce of [SSE, SSIM-sum, slices, voxels]"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from brief_pytorch_amd.dist_utils import allreduce_sum, broadcast_object
+    from brief_pytorch_amd.metrics import ssim2d
+    from brief_pytorch_amd.misc import merge_divided_data, parse_chunk_name
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    vol = make_volume((13, 24, 28), seed=6)                     # 13 slices over 3 ranks: ragged slabs
+    rng = np.random.default_rng(1)
+    dec = np.clip(vol.astype(np.int64) + rng.integers(-80, 80, size=vol.shape), 0, 65535).astype(np.uint16)
+    desc = None
+    if rank == 0:
+        chunks, _ = divide_data(vol, "total_2_2_1")
+        desc = [{"name": c["name"], "size": c["size"]} for c in chunks[:-1]]      # one block dropped: its region decodes as zeros
+    desc = broadcast_object(desc)
+    nz = vol.shape[0]
+    z0, z1 = nz * rank // world, nz * (rank + 1) // world
+    slab = np.zeros((z1 - z0,) + vol.shape[1:], np.uint16)
+    for c in desc:
+        r = parse_chunk_name(c["name"])
+        za, zb = max(r["d"][0], z0), min(r["d"][1] + 1, z1)
+        if za < zb:
+            slab[za - z0:zb - z0, r["h"][0]:r["h"][1] + 1, r["w"][0]:r["w"][1] + 1] = dec[za:zb, r["h"][0]:r["h"][1] + 1, r["w"][0]:r["w"][1] + 1]
+    d = slab.astype(np.int64) - vol[z0:z1].astype(np.int64)
+    ss = sum(ssim2d(vol[z, ..., 0], slab[z - z0, ..., 0], 65535) for z in range(z0, z1))
+    tot = allreduce_sum([float((d * d).sum()), ss, float(z1 - z0), float(d.size)], "cpu")
+    # what one process would have computed on the merged volume
+    parts = [{"data": dec[parse_chunk_name(c["name"])["d"][0]:parse_chunk_name(c["name"])["d"][1] + 1,
+                          parse_chunk_name(c["name"])["h"][0]:parse_chunk_name(c["name"])["h"][1] + 1,
+                          parse_chunk_name(c["name"])["w"][0]:parse_chunk_name(c["name"])["w"][1] + 1], **parse_chunk_name(c["name"])} for c in desc]
+    merged = merge_divided_data(parts, list(vol.shape))
+    full = merged.astype(np.int64) - vol.astype(np.int64)
+    ss_full = sum(ssim2d(vol[z, ..., 0], merged[z, ..., 0], 65535) for z in range(nz))
+    q.put((rank, tot.tolist(), float((full * full).sum()), ss_full, nz, float(vol.size), len(desc)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_three_rank_z_sharded_evaluation():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_eval, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(3)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, tot, sse_full, ss_full, nz, size, nblocks in res:
+        assert nblocks == 5                                        # every rank got rank 0's block list (3 x 2 x 1 blocks of the ragged split, minus the dropped one)
+        assert tot[0] == sse_full and tot[2] == nz and tot[3] == size
+        assert abs(tot[1] - ss_full) < 1e-9
