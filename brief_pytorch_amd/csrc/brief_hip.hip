@@ -187,9 +187,11 @@ __device__ __forceinline__ void bstore1(float v, __amdgpu_buffer_rsrc_t rs, int 
 
 // One layer's GEMM for the feature tiles this wave owns:  acc[t] += A(mt,:) * image.
 // A fragments stream from the packed weight buffer (L2 resident) PD (kt,q)-steps ahead of use.
+// kit: (k-tile, q) steps that hold real features, ceil(F / 8): the steps above it multiply zero weight columns with the
+// zero activations of the padding features, so skipping them changes nothing but the time (F = 22 runs 3 of its 4 steps)
 template <int NT>
 __device__ __forceinline__ void chain(f32x16 (&acc)[KCfg<NT>::MTW], __amdgpu_buffer_rsrc_t rs, int soff_layer /*bytes*/,
-                                      const float4 *Xs, int wm, int lane)
+                                      const float4 *Xs, int wm, int lane, int kit)
 {
     using K = KCfg<NT>;
     constexpr int NIT = NT * 4;
@@ -202,15 +204,17 @@ __device__ __forceinline__ void chain(f32x16 (&acc)[KCfg<NT>::MTW], __amdgpu_buf
     constexpr int smul = 1024;
     float4 areg[NIT][K::MTW];
     float4 breg[NIT];
+    // padding is at most 31 features = the last three steps: only those carry a run-time check
 #pragma unroll
     for (int it = 0; it < PD; ++it)
 #pragma unroll
         for (int t = 0; t < K::MTW; ++t)
-            if (K::EXACT || wm + K::WM * t < NT) areg[it][t] = bload4(rs, voff, soff_w + (K::WM * t * NT * 4 + it) * smul);
+            if ((K::EXACT || wm + K::WM * t < NT) && (it < NIT - 3 || it < kit)) areg[it][t] = bload4(rs, voff, soff_w + (K::WM * t * NT * 4 + it) * smul);
     breg[0] = Xs[lane];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        if (it + PD < NIT) {
+        if (it >= NIT - 3 && it >= kit) break;
+        if (it + PD < NIT && (it + PD < NIT - 3 || it + PD < kit)) {
 #pragma unroll
             for (int t = 0; t < K::MTW; ++t)
                 if (K::EXACT || wm + K::WM * t < NT)
@@ -318,6 +322,7 @@ __global__ __launch_bounds__(256, TRAIN ? (NT > 8 ? 1 : BRIEF_TRAIN_WPE) : (NT >
     const int wm = wave % K::WM, ws = wave / K::WM;
     const brief_siren_desc &d = a.d;
     const int L = d.layers, cin = d.cin, cout = d.cout;
+    const int kit = (d.features + 7) >> 3;       // chain steps that hold real (unpadded) features
     const int64_t npad = a.npad;
     const float *pk = a.pk;
     float4 *Xs = X + ws * (NT * 256);
@@ -455,7 +460,7 @@ __global__ __launch_bounds__(256, TRAIN ? (NT > 8 ? 1 : BRIEF_TRAIN_WPE) : (NT >
                         acc[t][4 * q + 2] = bnext[t][q].z; acc[t][4 * q + 3] = bnext[t][q].w;
                     }
                 }
-                chain<NT>(acc, rs_pk, (int)(brief_pk_hidden(d, l) * 4), Xs, wm, lane);
+                chain<NT>(acc, rs_pk, (int)(brief_pk_hidden(d, l) * 4), Xs, wm, lane, kit);
                 STAMP(1)
                 lds_barrier();   // every wave is done reading the previous image
                 STAMP(2)
@@ -649,7 +654,7 @@ __global__ __launch_bounds__(256, TRAIN ? (NT > 8 ? 1 : BRIEF_TRAIN_WPE) : (NT >
             for (int t = 0; t < K::MTW; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-            chain<NT>(acc, rs_pk, (int)((brief_pk_hidden(d, l) + K::FP * K::FP) * 4), Xs, wm, lane);
+            chain<NT>(acc, rs_pk, (int)((brief_pk_hidden(d, l) + K::FP * K::FP) * 4), Xs, wm, lane, kit);
             STAMP(9)
             // delta_{l-1} = acc * om cos(om z_{l-1})
             const float om = (l - 1) == 0 ? d.w0_first : d.w0_hidden;
@@ -812,6 +817,7 @@ __global__ __launch_bounds__(256, small_wpe(HB)) void k_small(const FusedArgs a)
     const int wm = wave % K::WM, ws = wave / K::WM;
     const brief_siren_desc &d = a.d;
     const int L = d.layers, cin = d.cin, cout = d.cout;
+    const int kit = (d.features + 7) >> 3;       // chain steps that hold real (unpadded) features
     const float *pk = a.pk;
     float4 *Xs = X + ws * (NT * 256);
     float *DTw = DT + wave * PANEL, *HTw = HT + wave * PANEL;
@@ -880,7 +886,7 @@ __global__ __launch_bounds__(256, small_wpe(HB)) void k_small(const FusedArgs a)
                         acc[0][4 * q] = bnext[q].x; acc[0][4 * q + 1] = bnext[q].y;
                         acc[0][4 * q + 2] = bnext[q].z; acc[0][4 * q + 3] = bnext[q].w;
                     }
-                    chain<NT>(acc, rs_pk, (int)(brief_pk_hidden(d, l) * 4), Xs, wm, lane);
+                    chain<NT>(acc, rs_pk, (int)(brief_pk_hidden(d, l) * 4), Xs, wm, lane, kit);
                     STAMP(1)
                     TILE_BARRIER()
                 }
@@ -1024,7 +1030,7 @@ __global__ __launch_bounds__(256, small_wpe(HB)) void k_small(const FusedArgs a)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
                 STAMP(4)
-                chain<NT>(acc, rs_pk, (int)((brief_pk_hidden(d, li) + K::FP * K::FP) * 4), Xs, wm, lane);
+                chain<NT>(acc, rs_pk, (int)((brief_pk_hidden(d, li) + K::FP * K::FP) * 4), Xs, wm, lane, kit);
                 STAMP(5)
                 // weight gradient: k = sample; lane (m, hi) feeds samples 16 hi + s at step s
 #pragma unroll
