@@ -1424,7 +1424,7 @@ struct ReduceArgs {
     int nrec_wg;
     const float *slabs;
     int nsplit;
-    int sgroups;          // hidden parameters: threads per parameter (1 for k_wgrad's <= 85 slabs, 8 for k_small's one per workgroup)
+    int sgroups;          // hidden parameters: threads per parameter (4 for k_wgrad's <= 85 slabs, 8 for k_small's one per workgroup)
     float *grads;
     float *loss_out;
     float inv_count;
@@ -1445,7 +1445,7 @@ __device__ __forceinline__ int64_t frag_index(int NT, int row, int col)
 // blocks [0, nb_hidden): one thread per hidden-layer parameter, nsplit slab terms each.
 // blocks [nb_hidden, ...): one WAVE per first-layer / head parameter (and one for the loss): these sum
 // over up to 2048 per-wave records, which a single thread would walk at one L2 latency per term.
-__global__ __launch_bounds__(256) void k_reduce(const ReduceArgs a, int nb_hidden)
+__global__ __launch_bounds__(1024) void k_reduce(const ReduceArgs a, int nb_hidden)
 {
     const brief_siren_desc &d = a.d;
     const int F = d.features, cin = d.cin, cout = d.cout;
@@ -1455,9 +1455,9 @@ __global__ __launch_bounds__(256) void k_reduce(const ReduceArgs a, int nb_hidde
     if ((int)blockIdx.x < nb_hidden) {
         // sgroups threads per parameter: thread (pl, sg) adds slabs sg, sg + sgroups, ...; group 0 then adds the
         // group sums in group order (fixed order: bit-reproducible)
-        __shared__ float fold[256];
+        __shared__ float fold[1024];
         const int64_t hcount = off_head - l0_count;
-        const int SG = a.sgroups, ppb = 256 / SG;
+        const int SG = a.sgroups, ppb = (int)blockDim.x / SG;      // ppb consecutive parameters per block: a group's loads stay coalesced
         const int pl = threadIdx.x % ppb, sg = threadIdx.x / ppb;
         const int64_t hidx = (int64_t)blockIdx.x * ppb + pl;
         const bool live = hidx < hcount;
@@ -1502,7 +1502,7 @@ __global__ __launch_bounds__(256) void k_reduce(const ReduceArgs a, int nb_hidde
     }
     // ---- skinny parameters: wave w of this block handles item (blockIdx - nb_hidden)*4 + w
     const int lane = threadIdx.x & 63;
-    const int64_t item = (int64_t)(blockIdx.x - nb_hidden) * 4 + (threadIdx.x >> 6);
+    const int64_t item = (int64_t)(blockIdx.x - nb_hidden) * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t head_count = (int64_t)cout * F + cout;
     const int nrec = a.nrec_wg * WS;                 // records that carry a given feature tile / the loss
     if (item > l0_count + head_count) return;
@@ -2175,7 +2175,8 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
             ra.d = *d; ra.slabs = ws + w16.slabs; ra.nsplit = nsp; ra.sgroups = 1;
             ra.grads = grads; ra.loss_out = loss_out; ra.inv_count = inv16;
             if (upd) { ra.update = 1; ra.opt = upd->opt; ra.params = upd->params; ra.s1 = upd->s1; ra.s2 = upd->s2; ra.pk = upd->pk; }
-            const int nbh = (int)((hcnt + 255) / 256);
+            ra.sgroups = 4;                                                             // 4 threads x ~2-4 slabs per parameter
+            const int nbh = (int)((hcnt + 63) / 64);
             hipLaunchKernelGGL(k_reduce, dim3(nbh), dim3(256), 0, st, ra, nbh);      // hidden-layer part only
             HIP_TRY(hipGetLastError());
         }
@@ -2239,16 +2240,21 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
     ReduceArgs ra;
     memset(&ra, 0, sizeof(ra));
     ra.d = *d; ra.rec = fa.rec; ra.nrec_wg = grid1; ra.slabs = ws + wl.slabs; ra.nsplit = nsplit;
-    ra.sgroups = small ? 8 : 1;
+    // threads per hidden parameter: k_small leaves one slab per workgroup (<= 2 x CUs of them): 8 threads x 64 slabs;
+    // k_wgrad <= 85 slabs: 4 threads x ~21.  The group sums are added in group order (bit-reproducible).  (32 threads per
+    // parameter in 1024-thread blocks were measured slower for the narrow nets: 0.090 against 0.083 ms per 4x22 step.)
+    ra.sgroups = small ? 8 : 4;
+    const int rthreads = 256;
     ra.grads = grads; ra.loss_out = loss_out; ra.inv_count = inv_count;
     if (upd) { ra.update = 1; ra.opt = upd->opt; ra.params = upd->params; ra.s1 = upd->s1; ra.s2 = upd->s2; ra.pk = upd->pk; }
     const int64_t l0_count = (int64_t)d->features * d->cin + d->features;
     const int64_t hcount = brief_canon_head_off(*d) - l0_count;
     const int64_t skinny = l0_count + (int64_t)d->cout * d->features + d->cout + 1;   // + the loss
-    const int ppb = 256 / ra.sgroups;                  // hidden parameters per k_reduce block
+    const int ppb = rthreads / ra.sgroups;             // hidden parameters per k_reduce block
     const int nb_hidden = (int)((hcount + ppb - 1) / ppb);
-    const int nb_skinny = (int)((skinny + 3) / 4);
-    hipLaunchKernelGGL(k_reduce, dim3(nb_hidden + nb_skinny), dim3(256), 0, st, ra, nb_hidden);
+    const int wpb = rthreads / 64;                     // skinny items (one wave each) per block
+    const int nb_skinny = (int)((skinny + wpb - 1) / wpb);
+    hipLaunchKernelGGL(k_reduce, dim3(nb_hidden + nb_skinny), dim3(rthreads), 0, st, ra, nb_hidden);
     HIP_TRY(hipGetLastError());
     return 0;
 }
