@@ -217,8 +217,9 @@ __device__ __forceinline__ void chain(f32x16 (&acc)[KCfg<NT>::MTW], __amdgpu_buf
         if (it + PD < NIT && (it + PD < NIT - 3 || it + PD < kit)) {
 #pragma unroll
             for (int t = 0; t < K::MTW; ++t)
-                if (K::EXACT || wm + K::WM * t < NT)
+                if (K::EXACT || wm + K::WM * t < NT) {
                     areg[it + PD][t] = bload4(rs, voff, soff_w + (K::WM * t * NT * 4 + it + PD) * smul);
+                }
         }
         if (it + 1 < NIT) breg[it + 1] = Xs[(it + 1) * 64 + lane];
         // pin the prefetch above this step's MFMAs: left alone, the scheduler sinks each load to
