@@ -115,9 +115,9 @@ def test_singletask_2d_rgb_image(tmp_path):
     yy, xx = np.meshgrid(np.linspace(0, 1, 48), np.linspace(0, 1, 64), indexing="ij")
     img = np.stack([120 + 100 * np.sin(6 * xx + 2 * yy), 128 + 90 * np.cos(5 * yy), 100 + 80 * np.sin(4 * (xx + yy))], -1)
     img = np.clip(img + rng.normal(0, 2, img.shape), 0, 255).astype(np.uint8)
-    path = str(tmp_path / "rgb.npy")
+    path = str(tmp_path / "rgb.png")                      # utils/tool.py:85-91, 100-101: the .png route of read_img / save_img
     save_img(path, img)
-    assert read_img(path).shape == (48, 64, 3)
+    assert np.array_equal(read_img(path), img)
     opt = _opt(tmp_path, 4000, "none", 4.0 * SIREN.calc_param_count(2, 3, 48, 4))
     cf = opt.CompressFramework
     cf.Module.phi.coords_channel, cf.Module.phi.data_channel, cf.Module.phi.layers = 2, 3, 4
@@ -135,7 +135,7 @@ def test_singletask_2d_rgb_image(tmp_path):
     side = config.load(os.path.join(sdir, "compressed", "sideinfos.yaml"))
     assert list(side["data_shape"]) == [48, 64, 3] and side["phi_features"] == 48 and side["dtype"] == "uint8"
     assert os.path.exists(os.path.join(sdir, "compressed", "module", "weight-0-48-2")) and os.path.exists(os.path.join(sdir, "compressed", "module", "weight-3-3-48"))
-    dec = read_img(os.path.join(sdir, "decompressed", "rgb_decompressed.npy"))
+    dec = read_img(os.path.join(sdir, "decompressed", "rgb_decompressed.png"))
     assert dec.shape == img.shape and dec.dtype == np.uint8
     again = NFGR.decompress(config.to_opt({"CompressFramework": cf}), os.path.join(sdir, "compressed", "module"), dict(side))
     assert np.array_equal(again, dec)
