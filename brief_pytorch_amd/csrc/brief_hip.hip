@@ -296,7 +296,7 @@ struct FusedLds {
 #ifndef BRIEF_TRAIN_WPE
 #define BRIEF_TRAIN_WPE 2   // waves per SIMD the TRAIN variant is register-allocated for
 #endif
-#ifdef BRIEF_STAMPS
+#if defined(BRIEF_STAMPS) && BRIEF_STAMPS + 0 != 2      /* -DBRIEF_STAMPS=2: only the start / end clock pair (the product instruction stream otherwise) */
 #define STAMP(slot) { const long long t_ = clock64(); st_acc[slot] += (float)(t_ - st_last); st_last = t_; }
 #else
 #define STAMP(slot)
@@ -718,6 +718,9 @@ __global__ __launch_bounds__(256, TRAIN ? (NT > 8 ? 1 : BRIEF_TRAIN_WPE) : (NT >
             for (int i = 0; i < 10; ++i) rec[BRIEF_REC_STAMPS + i] = st_acc[i];
             rec[BRIEF_REC_STAMPS + 10] = (float)(clock64() - st_c0);
             rec[BRIEF_REC_STAMPS + 11] = (float)(wall_clock64() - st_r0);
+            rec[BRIEF_REC_STAMPS + 12] = (float)(st_r0 & 0xFFFFFF);      // absolute start (100 MHz ticks, low 24 bits) and the XCC the workgroup ran on
+            rec[BRIEF_REC_STAMPS + 13] = (float)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15);      // HW_REG_XCC_ID[3:0]
+            rec[BRIEF_REC_STAMPS + 14] = (float)(__builtin_amdgcn_s_getreg(4 | (0 << 6) | (15 << 11)) & 0xFFFF);  // HW_REG_HW_ID[15:0]: wave, simd, pipe, cu[11:8], sh[12], se[15:13]
 #endif
         }
     }

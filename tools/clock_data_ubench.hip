@@ -63,7 +63,7 @@ template <typename F>
 static void run(const char *name, F kern, float *out, long long *t, int iters, double cyc_per_mfma, double flop_per_mfma)
 {
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    for (int rep = 0; rep < 3; ++rep) {                 // the third repetition is reported: the power state has settled
+    for (int rep = 0; rep < 40; ++rep) {                // the last repetition is reported: ~0.8 s in, the power state has settled
         (void)hipEventRecord(e0);
         hipLaunchKernelGGL(kern, dim3(1024), dim3(256), 0, 0, out, t, iters);
         (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);

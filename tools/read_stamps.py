@@ -1,6 +1,6 @@
 """scratch: read the cycle stamps of the diagnostic k_fused build"""
 import shutil, sys
-import os; os.environ["BRIEF_LIB"] = os.path.abspath("brief_pytorch_amd/libbrief_hip_stamps.so")
+import os; os.environ.setdefault("BRIEF_LIB", os.path.abspath("brief_pytorch_amd/libbrief_hip_stamps.so"))
 import torch, numpy as np
 sys.path.insert(0, '.')
 from brief_pytorch_amd import _lib
@@ -11,7 +11,7 @@ pop = 256**3
 m = SIREN(features=256, layers=5, w0=20).to('cuda')
 tv = torch.rand(pop, 1, device='cuda') * 100
 fit = Fitter(m, tv, (256,256,256), sample_size=100000)
-for _ in range(5): fit.step()
+for _ in range(int(os.environ.get("STAMP_STEPS", "600"))): fit.step()      # steady state: the first steps after idle run at ~1.85 GHz
 torch.cuda.synchronize()
 FP, npad, hidden = 256, 100000, 3
 rec_off = 2 * hidden * FP * npad

@@ -10,7 +10,7 @@ torch.manual_seed(0)
 m = SIREN(features=F, layers=L, w0=20, precision='bf16').to('cuda')
 tv = torch.rand(128 ** 3, 1, device='cuda') * 100
 fit = Fitter(m, tv, (128, 128, 128), sample_size=100000)
-for _ in range(4): fit.step()
+for _ in range(int(os.environ.get("STAMP_STEPS", "400"))): fit.step()
 torch.cuda.synchronize()
 FP = 256 if F <= 256 else 512
 npad = (100000 + 127) // 128 * 128

@@ -11,7 +11,7 @@ dims = (64, 64, 64)
 m = SIREN(features=F, layers=L, w0=20).to('cuda')
 tv = torch.rand(64 ** 3, 1, device='cuda') * 100
 fit = Fitter(m, tv, dims, sampler='full', sample_size=0)
-for _ in range(5): fit.step()
+for _ in range(int(os.environ.get("STAMP_STEPS", "2000"))): fit.step()
 torch.cuda.synchronize()
 nrec = 512 * 4
 rec = m._ws[:nrec * 1056].view(nrec, 1056).cpu().numpy()      # k_small path: the record region starts the workspace
