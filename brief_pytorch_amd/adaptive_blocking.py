@@ -96,6 +96,8 @@ def _gpu_stats(device):
 
     def to_dev(blk):
         a = np.ascontiguousarray(blk)
+        if not a.flags.writeable:        # a block of a read-only memory map: torch wants a buffer it may alias
+            a = a.copy()
         if a.dtype == np.uint16:         # (moved as int16 bits, widened on the device: no float64 copy on the host)
             return (torch.from_numpy(a.view(np.int16)).to(device).to(torch.int32) & 0xFFFF).double()
         return torch.from_numpy(a).to(device).double()

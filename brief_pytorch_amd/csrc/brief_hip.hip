@@ -487,10 +487,17 @@ __global__ __launch_bounds__(256, TRAIN ? (NT > 8 ? 1 : BRIEF_TRAIN_WPE) : (NT >
                             bstore1(acc[t][r], rz, voff, (32 * mt + (r & 3) + 8 * (r >> 2)) * rbz);
                     }
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float fr = acc[t][r];
-                        hreg[t][r] = BRIEF_SIN_REV(fr);
-                        if (TRAIN && last) creg[t][r] = om * BRIEF_COS_REV(fr);
+                    for (int r = 0; r < 16; ++r) hreg[t][r] = BRIEF_SIN_REV(acc[t][r]);
+                }
+            }
+            if (TRAIN && last) {
+                // a real (scalar) branch: if-converted, the 32 v_cos of every earlier layer were computed and thrown away
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int t = 0; t < K::MTW; ++t) {
+                    if (K::EXACT || wm + K::WM * t < NT) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) creg[t][r] = om * BRIEF_COS_REV(acc[t][r]);
                     }
                 }
             }
