@@ -38,6 +38,21 @@ def allreduce_sum(values, device):
     return t.cpu().numpy()
 
 
+def allreduce_max(arr, device):
+    """elementwise maximum of a small non-negative array over the ranks (max-intensity projections of z-slabs: a rank that
+    does not hold a row leaves it zero).  Integers travel as int64, floats as float64: exact for every image dtype."""
+    dist, _, _ = dist_info()
+    a = np.asarray(arr)
+    if dist is None:
+        return a
+    if dist.get_backend() == "gloo":
+        device = "cpu"
+    wide = np.int64 if np.issubdtype(a.dtype, np.integer) else np.float64
+    t = torch.from_numpy(np.ascontiguousarray(a.astype(wide))).to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t.cpu().numpy().astype(a.dtype)
+
+
 def allreduce_sse(sse, count, device):
     """sum [sse_0..sse_k, count] over ranks"""
     out = allreduce_sum(list(sse) + [float(count)], device)

@@ -22,7 +22,7 @@ from . import _lib, config
 from .fit import Fitter
 from .io import get_folder_size, get_type_max, invnormalize_data, minmaxany_range, normalize_data, save_yaml, load_yaml
 from .metrics import cal_ssim, eval_performance, gpu_eval_u16, gpu_ssim_u16, psnr_from_sse
-from .misc import (alloc_param, cal_divide_num, divide_data, merge_divided_data, mip_ops, parse_checkpoints,
+from .misc import (alloc_param, cal_divide_num, divide_data, merge_divided_data, mip_ops, save_mips, parse_checkpoints,
                    parse_chunk_name, parse_weight, preprocess, preprocess_is_identity)
 from .modelsave import CopyDir, load_model, save_model
 from .networks import (ALL_CALC_PHI_FEATURES, ALL_CALC_PHI_PARAM_COUNT, get_nnmodule_param_count, init_phi)
@@ -64,7 +64,7 @@ class MyLogger:
         pass
 
 
-from .dist_utils import allreduce_sum, assign_blocks, broadcast_object, dist_info as _dist  # noqa: E402
+from .dist_utils import allreduce_max, allreduce_sum, assign_blocks, broadcast_object, dist_info as _dist  # noqa: E402
 
 
 class NFGR:
@@ -245,9 +245,10 @@ class NFGR:
             if opt.Decompress.mip and data.ndim == 4:
                 mdir = opj(sdir, "mip")
                 os.makedirs(mdir, exist_ok=True)
-                for tag, vol in ((name, data), (name + "_decompressed", dec)):
-                    for ax, img in zip("dhw", mip_ops(vol)):
-                        save_img(opj(mdir, "%s_mip_%s%s" % (tag, ax, ext)), img)
+                for tag, vol in ((name, data), (name + "_decompressed", dec)):      # main.py:433-438: in the data's format and as .png
+                    mips = mip_ops(vol, mdir, tag, ext)
+                    if ext != ".png":
+                        save_mips(mips, mdir, tag, ".png")
             if data.dtype == np.uint16 and data.ndim == 4 and data.shape[-1] == 1 and min(data.shape[1:3]) >= 11:
                 perf = {"steps": steps, **gpu_eval_u16(data, dec, opt.Decompress.mse, opt.Decompress.psnr, opt.Decompress.ssim)}
                 if Log is not None:
@@ -500,12 +501,25 @@ class NFGR:
                 if three_d:
                     create_stack(out_paths[k], shape, data.dtype)
         _barrier(dist)
+        want_mip = bool(self.opt.Decompress.mip) and three_d
+        mips = {}                                       # tag -> this rank's share of the three projections (main.py:622-631)
+
+        def slab_mips(vol):
+            """max over z of the slab; the h- and w-projections hold this rank's z rows, zeros elsewhere"""
+            md = vol.max(0)
+            mh, mw = np.zeros((nz,) + vol.shape[2:], vol.dtype), np.zeros((nz, vol.shape[1]) + vol.shape[3:], vol.dtype)
+            mh[z0:z1], mw[z0:z1] = vol.max(1), vol.max(2)
+            return [md, mh, mw]
         if z1 > z0:
             orig = np.array(data[z0:z1] if three_d else data, copy=True)      # this rank's slab of the ORIGINAL data
             orig_t = torch.from_numpy(orig).to(self.device) if gpu_metrics else None
+            if want_mip:
+                mips[name] = slab_mips(orig)
             for ki, k in enumerate(checkpoints):
                 sdir = opj(logdir, "steps{}".format(k))
                 dec_t = self._decode_slab(sdir, chunks, z0, z1, shape, data.dtype)
+                if want_mip:
+                    mips[(k, name + "_decompressed")] = slab_mips(dec_t.cpu().numpy())
                 if gpu_metrics:
                     sse = torch.zeros(1, dtype=torch.float64, device=self.device)
                     _lib.check(_lib.lib().brief_sse_u16(_lib.ptr(orig_t), _lib.ptr(dec_t), orig_t.numel(), _lib.ptr(sse), _lib.stream_ptr()))
@@ -529,7 +543,20 @@ class NFGR:
                         save_img(out_paths[k], dec)
             acc[2 * K] = float(z1 - z0)
             acc[2 * K + 1] = float(orig.size)
-        tot = allreduce_sum(acc, self.device)         # RCCL over xGMI: the one collective of this path
+        tot = allreduce_sum(acc, self.device)         # RCCL over xGMI: the one data collective of this path
+        if want_mip:
+            # projections of the z-slabs: elementwise MAX over the ranks (the data is non-negative; a rank without a row holds zeros)
+            zero = [np.zeros(tuple(shape[1:]), data.dtype), np.zeros((nz,) + tuple(shape[2:]), data.dtype), np.zeros((nz, shape[1]) + tuple(shape[3:]), data.dtype)]
+            for tag in [name] + [(k, name + "_decompressed") for k in checkpoints]:
+                full = [allreduce_max(m, self.device) for m in mips.get(tag, zero)]
+                if rank == 0:
+                    for k in (checkpoints if tag == name else [tag[0]]):
+                        mdir = opj(logdir, "steps{}".format(k), "mip")
+                        os.makedirs(mdir, exist_ok=True)
+                        label = tag if tag == name else tag[1]
+                        save_mips(full, mdir, label, ext)
+                        if ext != ".png":
+                            save_mips(full, mdir, label, ".png")
         results = {}
         if rank == 0:
             for ki, k in enumerate(checkpoints):

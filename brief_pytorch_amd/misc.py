@@ -2,6 +2,8 @@
 block partition, parameter budget and merge (reference utils/misc.py:233-445,
 utils/adaptive_blocking.py:16-24, 425-459).  Pure numpy; pinned to golden vectors.
 """
+import os
+
 import numpy as np
 
 from .io import get_type_max, range_limit
@@ -72,10 +74,22 @@ def preprocess(data, denoise_level, denoise_close, clip_range):
     return data.clip(*range_limit(data, clip_range))
 
 
-def mip_ops(data):
-    """utils/misc.py:233-242 without the file writes: max-intensity projections along d, h, w"""
+def mip_ops(data, save_dir=None, data_name="", suffix=""):
+    """utils/misc.py:233-242: max-intensity projections along d, h, w, optionally written as
+    <save_dir>/<data_name>_mip_{d,h,w}<suffix>"""
     assert data.ndim == 4
-    return data.max(0), data.max(1), data.max(2)
+    mips = data.max(0), data.max(1), data.max(2)
+    if save_dir is not None:
+        save_mips(mips, save_dir, data_name, suffix)
+    return mips
+
+
+def save_mips(mips, save_dir, data_name, suffix):
+    from .tool import save_img
+    for ax, img in zip("dhw", mips):
+        if suffix == ".png" and img.dtype not in (np.uint8, np.uint16):
+            continue                                  # PNG holds 8 / 16-bit integers only
+        save_img(os.path.join(save_dir, "%s_mip_%s%s" % (data_name, ax, suffix)), img)
 
 
 # ---------------------------------------------------------------- partition

@@ -96,6 +96,12 @@ def _worker_eval(rank, world, port, q):
     d = slab.astype(np.int64) - vol[z0:z1].astype(np.int64)
     ss = sum(ssim2d(vol[z, ..., 0], slab[z - z0, ..., 0], 65535) for z in range(z0, z1))
     tot = allreduce_sum([float((d * d).sum()), ss, float(z1 - z0), float(d.size)], "cpu")
+    # the max-intensity projections of the slabs, assembled by an elementwise MAX over the ranks (NFGR._evaluate_divide)
+    from brief_pytorch_amd.dist_utils import allreduce_max
+    md = allreduce_max(slab.max(0) if z1 > z0 else np.zeros(vol.shape[1:], np.uint16), "cpu")
+    mh = np.zeros((nz,) + vol.shape[2:], np.uint16)
+    mh[z0:z1] = slab.max(1)
+    mh = allreduce_max(mh, "cpu")
     # what one process would have computed on the merged volume
     parts = [{"data": dec[parse_chunk_name(c["name"])["d"][0]:parse_chunk_name(c["name"])["d"][1] + 1,
                           parse_chunk_name(c["name"])["h"][0]:parse_chunk_name(c["name"])["h"][1] + 1,
@@ -103,6 +109,7 @@ def _worker_eval(rank, world, port, q):
     merged = merge_divided_data(parts, list(vol.shape))
     full = merged.astype(np.int64) - vol.astype(np.int64)
     ss_full = sum(ssim2d(vol[z, ..., 0], merged[z, ..., 0], 65535) for z in range(nz))
+    assert md.dtype == np.uint16 and np.array_equal(md, merged.max(0)) and np.array_equal(mh, merged.max(1))
     q.put((rank, tot.tolist(), float((full * full).sum()), ss_full, nz, float(vol.size), len(desc)))
     dist.barrier()
     dist.destroy_process_group()

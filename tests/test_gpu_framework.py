@@ -59,7 +59,11 @@ def test_singletask_matches_reference_run(tmp_path, golden):
     again = NFGR.decompress(config.to_opt({"CompressFramework": opt.CompressFramework}), mod, dict(side))
     assert np.array_equal(again, dec_file)
     assert os.path.exists(os.path.join(Log.logdir, "performance.csv"))
-    assert os.path.exists(os.path.join(sdir, "mip", "vol_mip_d.tif"))
+    # main.py:429-438: projections of the original and of the decoded volume, in the data's format and as .png
+    for tag, v in (("vol", vol), ("vol_decompressed", dec_file)):
+        for ax, axis in zip("dhw", (0, 1, 2)):
+            for e in (".tif", ".png"):
+                assert np.array_equal(np.squeeze(read_img(os.path.join(sdir, "mip", "%s_mip_%s%s" % (tag, ax, e)))), v.max(axis)[..., 0]), (tag, ax, e)
     # the reference's final weights decode to (almost) the same volume as ours: same basin
     d = np.abs(dec_file.astype(np.int64) - g["dec_u16"].astype(np.int64))
     assert np.median(d) < 40
@@ -171,6 +175,12 @@ def test_dividetask_single_rank(tmp_path):
     # decompress_divide (main.py:299-320): the stored artefact tree alone reproduces the merged volume bit for bit
     again = fw.decompress_divide(os.path.join(cdir, "sideinfos.yaml"), os.path.join(cdir, "module"), os.path.join(cdir, "sideinfos"))
     assert again.dtype == merged.dtype and np.array_equal(again, merged)
+    # main.py:622-631: the projections of the merged volume (assembled from the ranks' z-slabs)
+    mdir = os.path.join(Log.logdir, "steps200", "mip")
+    for tag, v in (("blk", vol), ("blk_decompressed", merged)):
+        for ax, axis in zip("dhw", (0, 1, 2)):
+            for e in (".tif", ".png"):
+                assert np.array_equal(np.squeeze(read_img(os.path.join(mdir, "%s_mip_%s%s" % (tag, ax, e)))), v.max(axis)[..., 0]), (tag, ax, e)
 
 
 def test_dividetask_cotrained_blocks_equal_serial_blocks(tmp_path, monkeypatch):

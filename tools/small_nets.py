@@ -9,13 +9,16 @@ def run(L, F, dims, sampler, n):
     m = SIREN(features=F, layers=L, w0=20).to('cuda')
     tv = torch.rand(pop, 1, device='cuda') * 100
     fit = Fitter(m, tv, dims, sampler=sampler, sample_size=n)
-    for _ in range(5): fit.step()
-    torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.6:          # past the clock ramp after idle (tools/clock_ramp.py)
+        fit.run(100)
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(50): fit.step()
+    fit.run(500)
     e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 50
+    ms = e0.elapsed_time(e1) / 500
     M = 3 * F + (L - 2) * F * F + F
     print("L=%d F=%d n=%d: %.3f ms/step %.1f Msamples/s %.1f TFLOP/s" % (L, F, fit.n, ms, fit.n / ms / 1e3, 2 * (3 * M - 3 * F) * fit.n / ms / 1e9), flush=True)
 big = len(sys.argv) > 1 and sys.argv[1] == 'all'
