@@ -59,3 +59,14 @@ def set_by_path(opt, dotted, value):
         node = node[k]
     node[keys[-1]] = value
     return opt
+
+
+def merge(base, override):
+    """OmegaConf.merge for plain trees: dictionaries are merged key by key, everything else is replaced (main.py:568-569)"""
+    out = to_opt(to_plain(base))
+    for k, v in to_plain(override).items():
+        if isinstance(v, dict) and isinstance(out.get(k), dict):
+            out[k] = merge(out[k], v)
+        else:
+            out[k] = to_opt(v)
+    return out

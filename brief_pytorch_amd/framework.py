@@ -351,6 +351,7 @@ class NFGR:
         orig_sideinfos["chunks_numbers"] = desc["n_all"]
         chunks = desc["chunks"]
         checkpoints = parse_checkpoints(C_.checkpoints, C_.max_steps)
+        exceptions = _exceptions(self.opt)
         # cost model for the assignment: steps x samples/step x parameters of the block's net
         costs = []
         for c in chunks:
@@ -368,12 +369,18 @@ class NFGR:
         for i, c in enumerate(chunks):
             if owner[i] != rank:
                 continue
-            sub = NFGR(_block_opt(self.opt, c["param_size"]), Log=None, args=self.args)
+            over = exceptions.get(c["name"])
+            sub = NFGR(_block_opt(self.opt, c["param_size"], over), Log=None, args=self.args)
+            if over and not set(checkpoints) <= set(parse_checkpoints(sub.opt.Compress.checkpoints, sub.opt.Compress.max_steps)):
+                raise ValueError("Compress.divide.exception[%s] changes max_steps / checkpoints: the block would not produce the checkpoints %s the job stores" % (c["name"], checkpoints))
             sub_dir = opj(logdir, "subexps", c["name"])
             os.makedirs(sub_dir, exist_ok=True)
             block = np.ascontiguousarray(_orig_block(src, c))
             mine.append((c, sub, sub_dir, sub.prepare_fit(opj(sub_dir, c["name"] + ext), data=block, logdir=sub_dir)))
             del block
+        # blocks with option overrides keep their own schedule and sampler: they are fitted one by one, the rest together
+        special = [m for m in mine if m[0]["name"] in exceptions]
+        mine = [m for m in mine if m[0]["name"] not in exceptions]
         cotrain = (len(mine) > 1 and all(m[3]["fit"].index_stream is None and m[3]["fit"]._sched_name not in ("StepLR", "CyclicLR") for m in mine)
                    and os.environ.get("BRIEF_COTRAIN", "1") != "0")
         if torch.cuda.is_available():
@@ -398,13 +405,15 @@ class NFGR:
                 if on_mark is not None and k in marks:
                     on_mark(k)
         else:
-            for c, sub, sub_dir, ctx in mine:
-                done = 0
-                for k in checkpoints:
-                    fit = ctx["fit"]
-                    loss = fit.run(k - done) if fit.index_stream is None else [fit.step() for _ in range(k - done)][-1]
-                    done = k
-                    sub.checkpoint(ctx, k, loss, evaluate=False)
+            special, mine = [], mine + special
+        for c, sub, sub_dir, ctx in (special if (cotrain or on_mark is not None) else mine):
+            done = 0
+            for k in checkpoints:
+                fit = ctx["fit"]
+                loss = fit.run(k - done) if fit.index_stream is None and fit._sched_name not in ("StepLR", "CyclicLR") else [fit.step() for _ in range(k - done)][-1]
+                done = k
+                sub.checkpoint(ctx, k, loss, evaluate=False)
+        mine = mine + special
         if torch.cuda.is_available():
             torch.cuda.synchronize()
         self.fit_seconds = time.perf_counter() - t0
@@ -596,7 +605,10 @@ def _wrap(cf):
     return _Wrapped({"CompressFramework": cf})
 
 
-def _block_opt(cf, param_size):
+def _block_opt(cf, param_size, override=None):
+    """the options of one block's fit (main.py:549-569): the job's options with the block's byte budget, no second
+    preprocessing, no evaluation; `override` = Compress.divide.exception[<block name>], a partial tree of the WHOLE option
+    file (only its CompressFramework part can matter here), merged last as the reference does"""
     o = copy.deepcopy(cf)
     o.Compress.divide.divide_type = "none"
     o.Compress.param.filesize_ratio = 0
@@ -604,7 +616,20 @@ def _block_opt(cf, param_size):
     o.Compress.preprocess.denoise.level = 0
     o.Compress.preprocess.denoise.close = False
     o.Compress.decompress = False
+    if override:
+        part = config.to_plain(override).get("CompressFramework", {})
+        if part:
+            seed = o.get("_seed")
+            o = config.merge(o, part)
+            if seed is not None:
+                o["_seed"] = seed
     return o
+
+
+def _exceptions(cf):
+    """Compress.divide.exception: 'none' or {block name: partial option tree} (main.py:535-537)"""
+    e = cf.Compress.divide.get("exception", "none")
+    return {} if e in (None, "none") else dict(e)
 
 
 def _barrier(dist):

@@ -214,6 +214,43 @@ def test_dividetask_cotrained_blocks_equal_serial_blocks(tmp_path, monkeypatch):
     assert runs["1"][1] == runs["0"][1]
 
 
+def test_dividetask_exception_overrides_one_block(tmp_path):
+    """Compress.divide.exception (main.py:535-537, 568-569): a partial option tree merged into ONE block's task options.
+    The other blocks' weight files stay byte-identical to the run without it; the overridden block is fitted with its own
+    learning rate and loss and therefore differs."""
+    from brief_pytorch_amd.synthetic import make_volume
+    vol = make_volume((16, 32, 48), seed=9)
+    path = str(tmp_path / "blk.tif")
+    save_img(path, vol)
+    names = [c["name"] for c in misc.divide_data(vol, "total_1_2_2")[0]]
+    runs = {}
+    for tag in ("plain", "exc"):
+        opt = _opt(tmp_path / tag, 120, "none", 24000.0)
+        cf = opt.CompressFramework
+        cf.Compress.divide.divide_type = "total_1_2_2"
+        cf.Compress.divide.param_alloc = "by_size"
+        if tag == "exc":
+            cf.Compress.divide.exception = config.to_opt({names[1]: {"CompressFramework": {"Compress": {"lr_phi": 0.004, "loss": {"name": "datasmoothl1"}}}}})
+        Log = MyLogger(**opt.Log)
+        torch.manual_seed(42)
+        res = NFGR(cf, Log=Log).compress_divide(path, opt)
+        mdir = os.path.join(Log.logdir, "steps120", "compressed", "module")
+        runs[tag] = ({(blk, f): open(os.path.join(mdir, blk, "module", f), "rb").read() for blk in sorted(os.listdir(mdir))
+                      for f in sorted(os.listdir(os.path.join(mdir, blk, "module")))}, res[120]["psnr"])
+    plain, exc = runs["plain"][0], runs["exc"][0]
+    assert sorted(plain) == sorted(exc) and len({b for b, _ in plain}) == 4
+    for (blk, f), raw in plain.items():
+        assert (raw == exc[(blk, f)]) == (blk != names[1]), (blk, f)
+    assert runs["exc"][1] > 20
+    # an override that changes the checkpoint schedule of one block cannot be stored in the job's tree: refused up front
+    opt = _opt(tmp_path / "bad", 120, "none", 24000.0)
+    cf = opt.CompressFramework
+    cf.Compress.divide.divide_type = "total_1_2_2"
+    cf.Compress.divide.exception = config.to_opt({names[0]: {"CompressFramework": {"Compress": {"max_steps": 60}}}})
+    with pytest.raises(ValueError, match="exception"):
+        NFGR(cf, Log=MyLogger(**opt.Log)).compress_divide(path, opt)
+
+
 def test_dividetask_vessel_shaped(tmp_path):
     """BASELINE config 5 in small: opt/DivideTask/vessel.yaml (adaptotal, <= 4 blocks sized by cal_divide_num,
     by_size budget, 7-layer nets, w0 = 10) on a 16x128x128 vessel-like stack, 400 steps."""
