@@ -280,6 +280,10 @@ class NFGR:
             t_fit += time.perf_counter() - t0
             if stop in checkpoints:
                 self.checkpoint(ctx, stop, loss, evaluate)
+                # main.py:452-453: the CLI keeps only the last step directory unless -stepstore was given (args.stepstore is
+                # True when the flag is ABSENT); library callers (args is None) keep everything
+                if self.args is not None and getattr(self.args, "stepstore", False) and stop < max_steps:
+                    shutil.rmtree(opj(ctx["logdir"], "steps{}".format(stop)), ignore_errors=True)
         self.fit_seconds = t_fit
         return ctx["results"]
 

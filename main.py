@@ -39,7 +39,9 @@ def main(argv=None):
     ap.add_argument("-dropslice", action="store_true")
     ap.add_argument("-debug", action="store_true")
     ap.add_argument("-substore", action="store_true", help="keep the per-block sub-experiment directories")
-    ap.add_argument("-stepstore", action="store_true", help="accepted for compatibility; step directories are always kept")
+    # the reference's flag is inverted (main.py:695: store_false, tested at main.py:452): WITHOUT -stepstore a SingleTask run
+    # deletes every steps{k} directory except the last one after evaluating it; WITH it they are all kept
+    ap.add_argument("-stepstore", action="store_false", help="keep the intermediate steps{k} directories of a SingleTask run")
     args = ap.parse_args(argv)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -288,7 +288,7 @@ def test_cli_singletask_end_to_end(tmp_path, monkeypatch):
     opt = config.load(os.path.join(ROOT, "opt", "SingleTask", "default.yaml"))
     opt.Dataset.data_path = str(tmp_path / "dataset" / "synthetic_24x32x40.tif")
     opt.CompressFramework.Compress.max_steps = 150
-    opt.CompressFramework.Compress.checkpoints = "none"
+    opt.CompressFramework.Compress.checkpoints = "every_50"
     opt.Log.outputs_dir = str(tmp_path / "outputs")
     opt.Log.time = False
     y = str(tmp_path / "cli.yaml")
@@ -297,6 +297,14 @@ def test_cli_singletask_end_to_end(tmp_path, monkeypatch):
     assert r.returncode == 0, r.stderr[-2000:]
     assert "steps 150" in r.stdout and "psnr" in r.stdout
     run = os.path.join(str(tmp_path / "outputs"), "single")
+    # main.py:452-453, 695: without -stepstore only the last step directory survives (all three were evaluated: performance.csv)
+    assert sorted(d for d in os.listdir(run) if d.startswith("steps")) == ["steps150"]
+    assert len(open(os.path.join(run, "performance.csv")).read().strip().splitlines()) == 4
+    opt.Log.project_name = "kept"
+    config.save(opt, y)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "main.py"), "-p", y, "-g", "0", "-stepstore"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert sorted(d for d in os.listdir(os.path.join(str(tmp_path / "outputs"), "kept")) if d.startswith("steps")) == ["steps100", "steps150", "steps50"]
     assert os.path.exists(os.path.join(run, "steps150", "compressed", "module", "weight-0-21-3")) or \
         any(f.startswith("weight-0-") for f in os.listdir(os.path.join(run, "steps150", "compressed", "module")))
     assert os.path.exists(os.path.join(run, "performance.csv"))
