@@ -2186,8 +2186,10 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
             ra.d = *d; ra.slabs = ws + w16.slabs; ra.nsplit = nsp; ra.sgroups = 1;
             ra.grads = grads; ra.loss_out = loss_out; ra.inv_count = inv16;
             if (upd) { ra.update = 1; ra.opt = upd->opt; ra.params = upd->params; ra.s1 = upd->s1; ra.s2 = upd->s2; ra.pk = upd->pk; }
-            ra.sgroups = 4;                                                             // 4 threads x ~2-4 slabs per parameter
-            const int nbh = (int)((hcnt + 63) / 64);
+            // one thread per parameter: k_wgrad16 leaves only a handful of slabs per layer (8x512: 39.6 us against 63.2 us
+            // with 4 threads per parameter and 106 us with 8; 4x256: 8.5 / 10.8 us)
+            ra.sgroups = 1;
+            const int nbh = (int)((hcnt + 255) / 256);
             hipLaunchKernelGGL(k_reduce, dim3(nbh), dim3(256), 0, st, ra, nbh);      // hidden-layer part only
             HIP_TRY(hipGetLastError());
         }
