@@ -42,12 +42,6 @@ def parse_weight(data, weight_type_list):
     return weight
 
 
-def weights_are_trivial(weight_type_list, data, weight_thres_normalized, normalized_max):
-    """True when the loss weights provably never matter: either every weight is 1, or the
-    threshold rule `w[yhat <= thr] = 1` (main.py:178-179) cannot be beaten because thr > every target
-    ... the second case is NOT safe in general (yhat may exceed thr), so only all-ones qualifies."""
-    w = parse_weight(data, weight_type_list)
-    return bool(np.all(w == 1.0))
 
 
 def preprocess_is_identity(data, denoise_level, denoise_close, clip_range):

@@ -67,8 +67,9 @@ def test_checkpoints_and_weights(golden):
         assert misc.parse_checkpoints(spec, int(ms)) == list(g["checkpoints_%d" % i])
     for i, spec in enumerate((["value_65535_65535_1"], ["value_17000_20000_0.1"], ["quantile_16000_0.2_0.8_0.5"], ["exp_20000_0.5"], ["none"])):
         assert np.array_equal(misc.parse_weight(g["weight_vol"], spec), g["weight_%d" % i]), spec
-    assert misc.weights_are_trivial(["value_65535_65535_1"], g["vol"], 0, 0)
-    assert not misc.weights_are_trivial(["value_17000_20000_0.1"], g["vol"], 0, 0)
+    # the shipped default weight spec is all ones (prepare_fit then passes no weight map to the kernel)
+    assert np.all(misc.parse_weight(g["vol"], ["value_65535_65535_1"]) == 1.0)
+    assert not np.all(misc.parse_weight(g["vol"], ["value_17000_20000_0.1"]) == 1.0)
 
 
 @pytest.mark.parametrize("dt", ["total_2_2_2", "every_5_8_7", "total_1_2_4"])
