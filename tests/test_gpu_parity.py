@@ -116,6 +116,43 @@ def test_train_step_shapes_vs_oracle(L, F, cin, cout, n, oa):
     _check_grads(m, d, go)
 
 
+def test_random_configurations_vs_oracle():
+    """a seeded random walk over the configuration space (tools/fuzz_parity.py runs the same generator for longer): layers 2..11,
+    widths around every tile boundary, cin 2/3, cout 1..4, output activation, both losses, weight maps, thresholds, batch sizes
+    1..6000 including every 32-multiple neighbourhood.  Forward, loss and every gradient tensor against the oracle."""
+    rng = np.random.default_rng(2024)
+    widths = list(range(1, 65)) + [65, 95, 96, 97, 127, 128, 129, 160, 191, 192, 200, 223, 224, 255, 256, 257, 300, 383, 384, 385, 450, 511, 512]
+    for case in range(80):
+        L = int(rng.integers(2, 12))
+        F = int(rng.choice(widths))
+        if F > 256 and L > 6:
+            L = int(rng.integers(2, 7))
+        cin, cout = int(rng.choice([2, 3])), int(rng.choice([1, 1, 1, 2, 3, 4]))
+        oa = bool(rng.random() < 0.15)
+        w0 = float(rng.choice([10.0, 20.0, 30.0]))
+        n = int(rng.choice([1, 2, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 255, 257, 1000, 2049, int(rng.integers(1, 6000))]))
+        kind, thr, beta = int(rng.integers(0, 2)), float(rng.choice([0.0, 30.0, 200.0])), float(rng.choice([0.01, 1.0, 20.0]))
+        use_w = bool(rng.random() < 0.6)
+        m, d, p = make_net(L, F, w0, cin, cout, oa, seed=case)
+        x = rng.uniform(-1, 1, size=(n, cin)).astype(np.float32)
+        y = (rng.uniform(-1, 1, size=(n, cout)) if oa else rng.uniform(0, 100, size=(n, cout))).astype(np.float32)
+        w = np.where(rng.uniform(size=(n, cout)) < 0.5, 0.25, 1.0).astype(np.float32) if use_w else np.ones((n, cout), np.float32)
+        tag = (case, L, F, cin, cout, oa, w0, n, kind, thr, beta, use_w)
+        assert relerr(m.forward(torch.from_numpy(x).to(DEV)).cpu().numpy(), O.forward(d, p, x)) < 2e-5, tag
+        loss, _ = m.train_step(n, torch.from_numpy(y).to(DEV), coords=torch.from_numpy(x).to(DEV), weights=torch.from_numpy(w).to(DEV) if use_w else None,
+                               loss=["datal2", "datasmoothl1"][kind], thr=thr, beta=beta)
+        lo, go, _, _ = O.loss_grad(d, p, x, y, w, kind, thr, beta)
+        # (a loss that is a small difference of O(1) numbers - one sample, sine head - is only as exact as yhat is)
+        assert abs(loss.item() - lo) <= 1e-5 * max(abs(lo), 1e-2 * float(np.mean(y.astype(np.float64) ** 2))), tag
+        gw, gb = O.unpack_params(d, go)
+        mw, mb = O.unpack_params(d, m.grads.cpu().numpy())
+        gmax = max(float(np.max(np.abs(t))) for t in list(gw) + list(gb))
+        for l in range(L):
+            for got, ref in ((mw[l], gw[l]), (mb[l], gb[l])):
+                scale = max(float(np.max(np.abs(ref))), 1e-6 * gmax, 1e-30)
+                assert float(np.max(np.abs(np.asarray(got, np.float64) - np.asarray(ref, np.float64)))) / scale < 1e-4, (tag, l)
+
+
 @pytest.mark.parametrize("L,F,cin,cout,n", [(2, 8, 3, 1, 33), (3, 22, 3, 1, 4000), (4, 32, 2, 3, 129), (5, 22, 3, 1, 70000), (6, 17, 3, 1, 555),
                                              (7, 30, 3, 2, 3000), (8, 9, 3, 1, 64), (9, 32, 3, 1, 2049), (3, 64, 3, 1, 50000), (4, 35, 3, 1, 1000),
                                              (5, 56, 2, 1, 40000), (6, 40, 3, 4, 200), (7, 56, 3, 1, 66000), (8, 64, 3, 1, 321), (9, 33, 3, 1, 1500),

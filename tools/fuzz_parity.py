@@ -1,0 +1,67 @@
+"""Randomised differential test of the C-ABI against the CPU oracle: random net shapes (layers, width, cin, cout, output_act, w0),
+batch sizes (1 ... a few thousand, ragged), loss kinds, weight maps and thresholds; forward, loss and every gradient tensor.
+    python tools/fuzz_parity.py [cases] [seed]      (GPU box; prints the failing configurations, exit code 1 if any)"""
+import sys
+sys.path.insert(0, '.')
+import numpy as np, torch
+from brief_pytorch_amd.networks import SIREN
+from oracle import oracle as O
+
+def relerr(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-30))
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+widths = list(range(1, 65)) + [65, 95, 96, 97, 127, 128, 129, 160, 191, 192, 200, 223, 224, 255, 256, 257, 300, 383, 384, 385, 450, 511, 512]
+bad = 0
+for case in range(cases):
+    L = int(rng.integers(2, 12))
+    F = int(rng.choice(widths))
+    if F > 256 and L > 6:
+        L = int(rng.integers(2, 7))                      # keep the oracle quick
+    cin, cout = int(rng.choice([2, 3])), int(rng.choice([1, 1, 1, 2, 3, 4]))
+    oa = bool(rng.random() < 0.15)
+    w0 = float(rng.choice([10.0, 20.0, 30.0]))
+    n = int(rng.choice([1, 2, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 255, 257, 1000, 2049, int(rng.integers(1, 6000))]))
+    kind = int(rng.integers(0, 2))
+    thr = float(rng.choice([0.0, 30.0, 200.0]))
+    beta = float(rng.choice([0.01, 1.0, 20.0]))
+    use_w = bool(rng.random() < 0.6)
+    torch.manual_seed(case)
+    m = SIREN(coords_channel=cin, data_channel=cout, features=F, layers=L, w0=w0, output_act=oa)
+    d = O.make_desc(cin, cout, L, F, w0, 30.0, oa)
+    p = m.params.numpy().copy()
+    m.to('cuda')
+    x = rng.uniform(-1, 1, size=(n, cin)).astype(np.float32)
+    y = (rng.uniform(-1, 1, size=(n, cout)) if oa else rng.uniform(0, 100, size=(n, cout))).astype(np.float32)
+    w = np.where(rng.uniform(size=(n, cout)) < 0.5, 0.25, 1.0).astype(np.float32) if use_w else np.ones((n, cout), np.float32)
+    tag = "case %d: L=%d F=%d cin=%d cout=%d oa=%d w0=%g n=%d loss=%d thr=%g beta=%g weights=%d" % (case, L, F, cin, cout, oa, w0, n, kind, thr, beta, use_w)
+    try:
+        yh = m.forward(torch.from_numpy(x).cuda()).cpu().numpy()
+        e_f = relerr(yh, O.forward(d, p, x))
+        loss, _ = m.train_step(n, torch.from_numpy(y).cuda(), coords=torch.from_numpy(x).cuda(), weights=torch.from_numpy(w).cuda() if use_w else None,
+                               loss=["datal2", "datasmoothl1"][kind], thr=thr, beta=beta)
+        lo, go, _, _ = O.loss_grad(d, p, x, y, w, kind, thr, beta)
+        e_l = abs(loss.item() - lo) / (abs(lo) + 1e-30)
+        gw, gb = O.unpack_params(d, go)
+        mw, mb = O.unpack_params(d, m.grads.cpu().numpy())
+        gmax = max(float(np.max(np.abs(t))) for t in list(gw) + list(gb))
+        e_g = 0.0
+        for l in range(L):
+            for a, b in ((mw[l], gw[l]), (mb[l], gb[l])):
+                # a tensor whose gradient is (numerically) zero everywhere has no max-abs of its own to be relative to
+                scale = max(float(np.max(np.abs(b))), 1e-6 * gmax, 1e-30)
+                e_g = max(e_g, float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))) / scale))
+        # (a loss that is a small difference of O(1) numbers - one sample, sine head - is only as exact as yhat is)
+        ok = e_f < 2e-5 and abs(loss.item() - lo) <= 1e-5 * max(abs(lo), 1e-2 * float(np.mean(y.astype(np.float64) ** 2))) and e_g < 1e-4 and np.isfinite(loss.item())
+    except Exception as ex:
+        ok, e_f, e_l, e_g = False, -1, -1, -1
+        tag += "  EXCEPTION %r" % (ex,)
+    if not ok:
+        bad += 1
+        print("FAIL %s  forward %.2e loss %.2e grads %.2e" % (tag, e_f, e_l, e_g), flush=True)
+    elif case % 25 == 0:
+        print("ok   %s  forward %.1e loss %.1e grads %.1e" % (tag, e_f, e_l, e_g), flush=True)
+print("%d cases, %d failures" % (cases, bad))
+sys.exit(1 if bad else 0)
