@@ -461,7 +461,11 @@ __global__ __launch_bounds__(256, TRAIN ? (NT > 8 ? 1 : BRIEF_TRAIN_WPE) : (NT >
                         acc[t][4 * q + 2] = bnext[t][q].z; acc[t][4 * q + 3] = bnext[t][q].w;
                     }
                 }
+                // matrix work first: the wave inside a chain outranks its SIMD mate's epilogue (-0.5 % step time; the opposite
+                // order, epilogues first, costs +0.5 %: tools/ab_lib.sh, profiles/r02_issue_model.md)
+                if (TRAIN) __builtin_amdgcn_s_setprio(3);
                 chain<NT>(acc, rs_pk, (int)(brief_pk_hidden(d, l) * 4), Xs, wm, lane, kit);
+                if (TRAIN) __builtin_amdgcn_s_setprio(0);
                 STAMP(1)
                 lds_barrier();   // every wave is done reading the previous image
                 STAMP(2)
@@ -662,7 +666,9 @@ __global__ __launch_bounds__(256, TRAIN ? (NT > 8 ? 1 : BRIEF_TRAIN_WPE) : (NT >
             for (int t = 0; t < K::MTW; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+            __builtin_amdgcn_s_setprio(3);
             chain<NT>(acc, rs_pk, (int)((brief_pk_hidden(d, l) + K::FP * K::FP) * 4), Xs, wm, lane, kit);
+            __builtin_amdgcn_s_setprio(0);
             STAMP(9)
             // delta_{l-1} = acc * om cos(om z_{l-1})
             const float om = (l - 1) == 0 ? d.w0_first : d.w0_hidden;
