@@ -12,7 +12,7 @@ for n in ns:
     torch.manual_seed(0)
     m = SIREN(features=F, layers=L, w0=20, precision=prec).to('cuda')
     fit = Fitter(m, tv, (256, 256, 256), sampler='randompoint', sample_size=n)
-    fit.run(600)          # past the clock ramp after idle (tools/clock_ramp.py)
+    fit.run(int(__import__("os").environ.get("STEP_WARM", "600")))          # past the clock ramp after idle (tools/clock_ramp.py)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     fit.run(steps)
