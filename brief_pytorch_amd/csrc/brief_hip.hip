@@ -100,6 +100,8 @@ struct FusedArgs {
     float scale_min, den, span, vmin;   // fused invnormalize
     int stagger_cus;     // workgroups per residency slot (= CU count)
     int stagger;         // s_sleep(127) units of start delay per slot
+    int pers_wgs;        // k_fused: workgroups [0, pers_wgs) walk tiles b, b + pers_wgs, ... < pers_tiles (the persistent body);
+    int64_t pers_tiles;  //          workgroup b >= pers_wgs takes the single tile pers_tiles + b - pers_wgs (see fused_plan)
     int diag;            // timing diagnostics only (BRIEF_DIAG): bit 0 = stash descriptors with zero records (the range check then
                          // drops every stash load and store: results are wrong, the instruction stream is unchanged)
 };
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(256, TRAIN ? (NT > 8 ? 1 : BRIEF_TRAIN_WPE) : (NT >
     // de-phase the co-resident workgroups: started together they run their MFMA chains and their
     // epilogues in lockstep and the matrix pipe idles through every epilogue
     {
-        const int slot = blockIdx.x / a.stagger_cus;
+        const int slot = (int)blockIdx.x < a.pers_wgs ? blockIdx.x / a.stagger_cus : 0;
         for (int i = 0; i < slot * a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     }
     lds_barrier();
@@ -357,9 +359,18 @@ __global__ __launch_bounds__(256, TRAIN ? (NT > 8 ? 1 : BRIEF_TRAIN_WPE) : (NT >
     float accbh[4] = {0.f, 0.f, 0.f, 0.f};
     float lsum = 0.f;
 
-    const int64_t wg_samples = 32 * K::WS;
-    const int64_t ntiles = (a.n + wg_samples - 1) / wg_samples;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // Body (+ optional tail) in ONE launch.  The first pers_wgs workgroups are persistent and own a fixed set of tiles each;
+    // workgroups above them (BRIEF_TAIL_ROUNDS > 0, a diagnostic: off by default) own ONE tile each and are dealt by the
+    // hardware dispatcher to whichever CU retires a workgroup first — a dynamic queue without an atomic ticket, every
+    // workgroup still sums a FIXED set of tiles into its record.  Measured (profiles/r03_wg_timeline.md): a tile's
+    // LATENCY is 80 us alone on a CU and 95-104 us beside a mate whatever the plan, so the ragged end of the kernel is
+    // about half a tile long under any tile-granular scheduling; the single-tile workgroups pay ~6 us per round for their
+    // prologues and end 14-18 us later than the static plan, whose slot imbalance (first-dispatched workgroup of a CU: 6
+    // tiles in 570 us, its mate: 625 us) happens to cancel against the 53 first-slot workgroups that carry a 7th tile.
+    const bool pers = (int)blockIdx.x < a.pers_wgs;
+    const int64_t tile_end = pers ? a.pers_tiles : a.pers_tiles + ((int64_t)blockIdx.x - a.pers_wgs) + 1;
+    const int64_t tile_step = pers ? a.pers_wgs : 1;
+    for (int64_t tile = pers ? (int64_t)blockIdx.x : a.pers_tiles + ((int64_t)blockIdx.x - a.pers_wgs); tile < tile_end; tile += tile_step) {
         const int64_t n0 = (tile * K::WS + ws) * 32;
         const int64_t n = n0 + ln;
         const bool valid = n < a.n;
@@ -1850,6 +1861,7 @@ static int env_int(const char *name, int dflt, int lo, int hi)
     const int v = atoi(e);
     return v >= lo && v <= hi ? v : dflt;
 }
+static const int kRecWgsPerCu = 8;      // per-workgroup record slots per CU in the workspace (k_fused: body + single-tile tail)
 static const int g_wg_per_cu = env_int("BRIEF_WG_PER_CU", BRIEF_TRAIN_WPE, 1, 4);
 static const int g_stagger = env_int("BRIEF_STAGGER", 1, 0, 64);
 static const int g_diag = env_int("BRIEF_DIAG", 0, 0, 255);
@@ -1860,6 +1872,29 @@ static int fused_grid(const brief_siren_desc &d, int64_t n, bool train)
     const int64_t tiles = (n + brief_wg_samples(nt) - 1) / brief_wg_samples(nt);
     const int64_t cap = (int64_t)kCUs * (nt > 8 ? 1 : g_wg_per_cu);      // >8 tiles: 512-register kernel, one workgroup per CU
     return (int)(tiles < cap ? (tiles > 0 ? tiles : 1) : cap);
+}
+// k_fused<TRAIN> launch plan: a persistent body of `cap` workgroups over whole rounds of tiles, the rest of the batch
+// (the last BRIEF_TAIL_ROUNDS full rounds and the remainder) as single-tile workgroups behind them in the same grid
+struct FusedPlan { int grid, pers_wgs; int64_t pers_tiles; };
+static const int g_tail_rounds = env_int("BRIEF_TAIL_ROUNDS", 0, 0, 64);
+static FusedPlan fused_plan(const brief_siren_desc &d, int64_t n, bool train)
+{
+    const int nt = brief_nt(d);
+    const int64_t tiles = (n + brief_wg_samples(nt) - 1) / brief_wg_samples(nt);
+    const int cap = fused_grid(d, n, train);
+    FusedPlan p;
+    p.grid = cap; p.pers_wgs = cap; p.pers_tiles = tiles;
+    if (!train || nt > 8 || tiles <= cap) return p;        // decode: millions of tiles, the tail does not matter; > 8 tiles: one workgroup per CU
+    if (g_tail_rounds == 0) return p;
+    int64_t rounds = tiles / cap - g_tail_rounds;
+    if (rounds < 0) rounds = 0;
+    const int64_t max_wgs = (int64_t)kCUs * kRecWgsPerCu;               // record slots (ws_layout)
+    while (tiles - rounds * cap + (rounds ? cap : 0) > max_wgs) ++rounds;
+    if (rounds * cap >= tiles) return p;
+    p.pers_wgs = rounds ? cap : 0;
+    p.pers_tiles = rounds * cap;
+    p.grid = p.pers_wgs + (int)(tiles - p.pers_tiles);
+    return p;
 }
 static int wgrad_splits(const brief_siren_desc &d, int64_t n)
 {
@@ -1957,7 +1992,7 @@ static WsLayout ws_layout(const brief_siren_desc &d, int64_t n)
     w.z = 0;
     w.dd = w.z + (small ? 0 : hidden * FP * npad);
     w.rec = w.dd + (small ? 0 : hidden * FP * npad);
-    w.slabs = w.rec + (int64_t)kCUs * 4 /*max wg/CU*/ * 4 * BRIEF_REC_FLOATS;
+    w.slabs = w.rec + (int64_t)kCUs * kRecWgsPerCu * 4 * BRIEF_REC_FLOATS;
     w.total = w.slabs + hidden * (int64_t)(small ? small_grid(d, n) : wgrad_splits(d, n)) * (FP * FP + FP);
     return w;
 }
@@ -2119,7 +2154,9 @@ int brief_siren_forward(const brief_siren_desc *d, const float *packed, const br
     fa.vmin = (float)vmin;
     fa.stagger_cus = kCUs; fa.stagger = 0;
     if (d->precision == BRIEF_PREC_BF16) return launch_k16_split<false>(fa, (hipStream_t)stream);
-    return launch_fused<false>(fa, fused_grid(*d, batch->n, false), (hipStream_t)stream);
+    const FusedPlan fp = fused_plan(*d, batch->n, false);
+    fa.pers_wgs = fp.pers_wgs; fa.pers_tiles = fp.pers_tiles;
+    return launch_fused<false>(fa, fp.grid, (hipStream_t)stream);
 }
 
 struct UpdatePayload { OptimScalars opt; float *params, *s1, *s2, *pk; };
@@ -2210,7 +2247,8 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
         return 0;
     }
     const bool small = use_small(*d);
-    const int grid1 = small ? small_grid(*d, batch->n) : fused_grid(*d, batch->n, true);
+    const FusedPlan fp = fused_plan(*d, batch->n, true);
+    const int grid1 = small ? small_grid(*d, batch->n) : fp.grid;
     const int nsplit = small ? (d->layers > 2 ? grid1 : 0) : wgrad_splits(*d, batch->n);
     const float inv_count = (float)(1.0 / ((double)batch->n * d->cout));
 
@@ -2225,6 +2263,7 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
     fa.Z = ws + wl.z; fa.D = ws + wl.dd; fa.npad = brief_npad(nt, batch->n);
     fa.rec = ws + wl.rec; fa.slabs = ws + wl.slabs; fa.yhat_out = yhat_out;
     fa.stagger_cus = kCUs; fa.stagger = g_stagger; fa.diag = g_diag;
+    fa.pers_wgs = fp.pers_wgs; fa.pers_tiles = fp.pers_tiles;
     const bool prof = g_prof_on && g_prof_n < kProfSlots;
     if (prof) HIP_TRY(hipEventRecord(g_prof_ev[2 * g_prof_n], st));
     if (small) {
@@ -2243,7 +2282,7 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
         WgradArgs wa;
         memset(&wa, 0, sizeof(wa));
         wa.d = *d; wa.Z = fa.Z; wa.D = fa.D; wa.npad = fa.npad; wa.nsplit = nsplit; wa.slabs = ws + wl.slabs;
-        wa.stamps = ws + wl.rec + (int64_t)kCUs * 4 * 4 * BRIEF_REC_FLOATS - 256 * 8 * 8;   // tail of the record region (diagnostics)
+        wa.stamps = ws + wl.rec + (int64_t)kCUs * kRecWgsPerCu * 4 * BRIEF_REC_FLOATS - 256 * 8 * 8;   // tail of the record region (diagnostics)
         const int blocks = nsplit * (d->layers - 2) * wgrad_nq(nt) * wgrad_nq(nt);
 #define BRIEF_CASE(NTV)                                                                                    \
     case NTV:                                                                                              \
