@@ -461,7 +461,6 @@ __global__ __launch_bounds__(256, TRAIN ? (NT > 8 ? 1 : BRIEF_TRAIN_WPE) : (NT >
         STAMP(0)
         // ---- sine layers 0 .. L-2
         for (int l = 0; l <= L - 2; ++l) {
-            const float om = l == 0 ? d.w0_first : d.w0_hidden;
             const bool last = (l == L - 2);
             if (l > 0) {
 #pragma unroll
@@ -487,10 +486,11 @@ __global__ __launch_bounds__(256, TRAIN ? (NT > 8 ? 1 : BRIEF_TRAIN_WPE) : (NT >
             for (int t = 0; t < K::MTW; ++t) {
                 const int mt = wm + K::WM * t;
                 if (K::EXACT || mt < NT) {
-                    // the phase om z reduced to revolutions in [-1/2, 1/2]: what sin and cos are taken of, here and (TRAIN) again
-                    // from the stash by the dgrad chain (cos) and by k_wgrad (sin) without repeating the reduction
+                    // the accumulator IS the phase om z in revolutions (the weights carry om / 2 pi: brief_layout.h); its fraction
+                    // is what sin and cos are taken of, here and (TRAIN) again from the stash by the dgrad chain (cos) and by
+                    // k_wgrad (sin).  One VALU instruction per element where the exact two-term reduction took five.
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[t][r] = brief_revolutions(om * acc[t][r]);
+                    for (int r = 0; r < 16; ++r) acc[t][r] = __builtin_amdgcn_fractf(acc[t][r]);
                     if (TRAIN && !last) {
                         const __amdgpu_buffer_rsrc_t rz =
                             __builtin_amdgcn_make_buffer_rsrc((void *)(a.Z + (int64_t)l * K::FP * npad), 0, stash_bytes, 0x00020000);
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(256, TRAIN ? (NT > 8 ? 1 : BRIEF_TRAIN_WPE) : (NT >
                 for (int t = 0; t < K::MTW; ++t) {
                     if (K::EXACT || wm + K::WM * t < NT) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) creg[t][r] = om * BRIEF_COS_REV(acc[t][r]);
+                        for (int r = 0; r < 16; ++r) creg[t][r] = BRIEF_COS_REV(acc[t][r]);      // its om rides on g (gom below)
                     }
                 }
             }
@@ -602,19 +602,35 @@ __global__ __launch_bounds__(256, TRAIN ? (NT > 8 ? 1 : BRIEF_TRAIN_WPE) : (NT >
             float4 sW = make_float4(0.f, 0.f, 0.f, 0.f), sb = make_float4(0.f, 0.f, 0.f, 0.f);
             const int row = lane + 64 * rs;
             const float *trow = Tw + (row < K::TROWS ? row : 0) * 33;
+            if (cout == 1) {
+                // one channel (every volume BRIEF compresses but RGB images): a quarter of the multiply-adds
+#pragma unroll 8
+                for (int s = 0; s < 32; ++s) {
+                    const float gv = Gw[s * 4];
+                    sW.x = __fmaf_rn(trow[s], gv, sW.x);
+                    sb.x += gv;
+                }
+            } else {
 #pragma unroll 4
-            for (int s = 0; s < 32; ++s) {
-                const float hv = trow[s];
-                const float4 gv = *reinterpret_cast<const float4 *>(Gw + s * 4);
-                sW.x = __fmaf_rn(hv, gv.x, sW.x); sW.y = __fmaf_rn(hv, gv.y, sW.y);
-                sW.z = __fmaf_rn(hv, gv.z, sW.z); sW.w = __fmaf_rn(hv, gv.w, sW.w);
-                sb.x += gv.x; sb.y += gv.y; sb.z += gv.z; sb.w += gv.w;
+                for (int s = 0; s < 32; ++s) {
+                    const float hv = trow[s];
+                    const float4 gv = *reinterpret_cast<const float4 *>(Gw + s * 4);
+                    sW.x = __fmaf_rn(hv, gv.x, sW.x); sW.y = __fmaf_rn(hv, gv.y, sW.y);
+                    sW.z = __fmaf_rn(hv, gv.z, sW.z); sW.w = __fmaf_rn(hv, gv.w, sW.w);
+                    sb.x += gv.x; sb.y += gv.y; sb.z += gv.z; sb.w += gv.w;
+                }
             }
             if (row < K::TROWS) { accWh[rs][0] += sW.x; accWh[rs][1] += sW.y; accWh[rs][2] += sW.z; accWh[rs][3] += sW.w; }
             if (rs == 0) { accbh[0] += sb.x; accbh[1] += sb.y; accbh[2] += sb.z; accbh[3] += sb.w; }
         }
-        // ---- delta of the last sine layer: c * (Wh^T g)
+        // ---- delta of the last sine layer: om cos(phase) * (Wh^T g); the om rides on g (4 multiplies per sample, not 16 MTW)
         f32x16 dl[K::MTW];
+        float gom[4];
+        {
+            const float om_top = (L - 2) == 0 ? d.w0_first : d.w0_hidden;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) gom[c] = om_top * g[c];
+        }
 #pragma unroll
         for (int t = 0; t < K::MTW; ++t) {
             const int mt = wm + K::WM * t;
@@ -628,8 +644,8 @@ __global__ __launch_bounds__(256, TRAIN ? (NT > 8 ? 1 : BRIEF_TRAIN_WPE) : (NT >
                     for (int c = 0; c < 4; ++c) {
                         if (c < cout) {
                             const float4 wv = *reinterpret_cast<const float4 *>(HW + c * K::FP + 32 * mt + 8 * q + 4 * hi);
-                            sacc.x = __fmaf_rn(wv.x, g[c], sacc.x); sacc.y = __fmaf_rn(wv.y, g[c], sacc.y);
-                            sacc.z = __fmaf_rn(wv.z, g[c], sacc.z); sacc.w = __fmaf_rn(wv.w, g[c], sacc.w);
+                            sacc.x = __fmaf_rn(wv.x, gom[c], sacc.x); sacc.y = __fmaf_rn(wv.y, gom[c], sacc.y);
+                            sacc.z = __fmaf_rn(wv.z, gom[c], sacc.z); sacc.w = __fmaf_rn(wv.w, gom[c], sacc.w);
                         }
                     }
                     dl[t][4 * q] = creg[t][4 * q] * sacc.x; dl[t][4 * q + 1] = creg[t][4 * q + 1] * sacc.y;
@@ -681,15 +697,14 @@ __global__ __launch_bounds__(256, TRAIN ? (NT > 8 ? 1 : BRIEF_TRAIN_WPE) : (NT >
             chain<NT>(acc, rs_pk, (int)((brief_pk_hidden(d, l) + K::FP * K::FP) * 4), Xs, wm, lane, kit);
             __builtin_amdgcn_s_setprio(0);
             STAMP(9)
-            // delta_{l-1} = acc * om cos(om z_{l-1})
-            const float om = (l - 1) == 0 ? d.w0_first : d.w0_hidden;
+            // delta_{l-1} = acc * cos(phase_{l-1}): the chain ran on w0_{l-1} W_l^T, the stash holds the phase in revolutions
 #pragma unroll
             for (int t = 0; t < K::MTW; ++t) {
                 const int mt = wm + K::WM * t;
                 if (K::EXACT || mt < NT) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        dl[t][r] = acc[t][r] * om * BRIEF_COS_REV(zr[t][r]);      // the stash holds revolutions
+                        dl[t][r] = acc[t][r] * BRIEF_COS_REV(zr[t][r]);
                 }
             }
         }
@@ -906,7 +921,6 @@ __global__ __launch_bounds__(256, small_wpe(HB)) void k_small(const FusedArgs a)
 #pragma unroll
         for (int l = 0; l <= HB; ++l) {
             if (l <= L - 2) {
-                const float om = l == 0 ? d.w0_first : d.w0_hidden;
                 const bool last = (l == L - 2);
                 if (l > 0) {
 #pragma unroll
@@ -923,10 +937,10 @@ __global__ __launch_bounds__(256, small_wpe(HB)) void k_small(const FusedArgs a)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) bnext[q] = *reinterpret_cast<const float4 *>(bp_ + 32 * wm + 8 * q + 4 * hi);
                 }
-                // keep the phase om z reduced to revolutions: the backward pass takes sin and cos of it again without
-                // repeating the reduction (same bits: the reduction is a function of om z alone)
+                // the accumulator is the phase om z in revolutions (the weights carry om / 2 pi); keep its fraction: the
+                // backward pass takes sin and cos of it again
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[0][r] = brief_revolutions(om * acc[0][r]);
+                for (int r = 0; r < 16; ++r) acc[0][r] = __builtin_amdgcn_fractf(acc[0][r]);
                 zst[l] = acc[0];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) hreg[0][r] = BRIEF_SIN_REV(acc[0][r]);
@@ -1020,6 +1034,12 @@ __global__ __launch_bounds__(256, small_wpe(HB)) void k_small(const FusedArgs a)
         // ---- Wh^T g: the last sine layer's delta is c_{L-2} times this (taken inside the unrolled loop below,
         //      where the layer index is a compile-time constant and z comes straight out of its registers)
         f32x16 dl[1];
+        float gom[4];      // om of the last sine layer rides on g
+        {
+            const float om_top = (L - 2) == 0 ? d.w0_first : d.w0_hidden;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) gom[c] = om_top * g[c];
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1027,30 +1047,28 @@ __global__ __launch_bounds__(256, small_wpe(HB)) void k_small(const FusedArgs a)
             for (int c = 0; c < 4; ++c) {
                 if (c < cout) {
                     const float4 wv = *reinterpret_cast<const float4 *>(HW + c * K::FP + 32 * wm + 8 * q + 4 * hi);
-                    sacc.x = __fmaf_rn(wv.x, g[c], sacc.x); sacc.y = __fmaf_rn(wv.y, g[c], sacc.y);
-                    sacc.z = __fmaf_rn(wv.z, g[c], sacc.z); sacc.w = __fmaf_rn(wv.w, g[c], sacc.w);
+                    sacc.x = __fmaf_rn(wv.x, gom[c], sacc.x); sacc.y = __fmaf_rn(wv.y, gom[c], sacc.y);
+                    sacc.z = __fmaf_rn(wv.z, gom[c], sacc.z); sacc.w = __fmaf_rn(wv.w, gom[c], sacc.w);
                 }
             }
             dl[0][4 * q] = sacc.x; dl[0][4 * q + 1] = sacc.y; dl[0][4 * q + 2] = sacc.z; dl[0][4 * q + 3] = sacc.w;
         }
 #define SMALL_TOP_DELTA(layer)                                                                           \
     if ((layer) == L - 2) {                                                                              \
-        const float omt = (layer) == 0 ? d.w0_first : d.w0_hidden;                                       \
         _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                   \
-            dl[0][r] *= omt * BRIEF_COS_REV(zst[(layer)][r]);                                            \
+            dl[0][r] *= BRIEF_COS_REV(zst[(layer)][r]);                                                  \
     }
         // ---- backward through the hidden layers L-2 .. 1: dW_l += delta_l h_{l-1}^T, delta_{l-1} = (W_l^T delta_l) . c_{l-1}
 #pragma unroll
         for (int li = HB; li >= 1; --li) {
             SMALL_TOP_DELTA(li)
             if (li <= L - 2) {
-                const float om1 = (li - 1) == 0 ? d.w0_first : d.w0_hidden;
-                f32x16 cp;
+                f32x16 cp;      // cos(phase_{li-1}): its om rides on the W^T copy the chain below runs on
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float fr = zst[li - 1][r];
                     HTw[ROWMAP(r, hi) * 36 + ln] = BRIEF_SIN_REV(fr);
-                    cp[r] = om1 * BRIEF_COS_REV(fr);
+                    cp[r] = BRIEF_COS_REV(fr);
                     DTw[ROWMAP(r, hi) * 36 + ln] = dl[0][r];
                 }
                 write_image<NT>(Xs, dl, wm, lane);
@@ -1515,15 +1533,17 @@ __global__ __launch_bounds__(1024) void k_reduce(const ReduceArgs a, int nb_hidd
             float *blk = a.pk + brief_pk_hidden(d, l);
             if (r < (int64_t)F * F) {
                 const int o = (int)(r / F), i = (int)(r % F);
-                blk[frag_index(NT, o, i)] = pv;                               // A-fragments of W
-                blk[(int64_t)FP * FP + frag_index(NT, i, o)] = pv;            // A-fragments of W^T
+                // the same products as k_repack's, bit for bit (brief_layout.h: what the copies carry)
+                const float pf = brief_phase_scale(d, l) * pv, pb = brief_om_prev(d, l) * pv;
+                blk[frag_index(NT, o, i)] = pf;                               // A-fragments of s_l W
+                blk[(int64_t)FP * FP + frag_index(NT, i, o)] = pb;            // A-fragments of w0_{l-1} W^T
                 if (d.precision == BRIEF_PREC_BF16) {
                     __bf16 *b16 = reinterpret_cast<__bf16 *>(a.pk + brief_pk16_off(d, l));
-                    b16[brief_frag16_index(NT, o, i)] = (__bf16)pv;
-                    b16[(int64_t)FP * FP + brief_frag16_index(NT, i, o)] = (__bf16)(brief_om_prev(d, l) * pv);
+                    b16[brief_frag16_index(NT, o, i)] = (__bf16)pf;
+                    b16[(int64_t)FP * FP + brief_frag16_index(NT, i, o)] = (__bf16)pb;
                 }
             } else {
-                blk[2 * (int64_t)FP * FP + (r - (int64_t)F * F)] = pv;        // bias
+                blk[2 * (int64_t)FP * FP + (r - (int64_t)F * F)] = brief_phase_scale(d, l) * pv;        // bias
             }
         }
         return;
@@ -1567,8 +1587,8 @@ __global__ __launch_bounds__(1024) void k_reduce(const ReduceArgs a, int nb_hidd
         if (a.update) {
             const float pv = optim_apply(a.opt, s, a.params, a.s1, a.s2, e);
             if (item < l0_count) {
-                if (item < (int64_t)F * cin) a.pk[(item / cin) * 4 + (item % cin)] = pv;     // W0p[o][c]
-                else a.pk[(item - (int64_t)F * cin) * 4 + 3] = pv;                           // W0p[o][3] = bias
+                if (item < (int64_t)F * cin) a.pk[(item / cin) * 4 + (item % cin)] = brief_phase_scale(d, 0) * pv;     // W0p[o][c]
+                else a.pk[(item - (int64_t)F * cin) * 4 + 3] = brief_phase_scale(d, 0) * pv;                           // W0p[o][3] = bias
             } else {
                 const int64_t r = item - l0_count;
                 float *hp = a.pk + brief_pk_head(d);
@@ -1608,8 +1628,8 @@ __global__ void k_repack(const brief_siren_desc d, const float *__restrict__ par
                 const int row = 32 * mt + (lanei & 31);
                 const int col = 32 * kt + 16 * sstep + 8 * (j >> 2) + 4 * (lanei >> 5) + (j & 3);
                 float w = 0.f;
-                // the backward copy carries om_{l-1}: delta_{l-1} = (om W_l^T delta_l) . cos(om z_{l-1})  (brief_bf16.inc)
-                if (row < F && col < F) w = bwd ? brief_om_prev(d, l) * W[(int64_t)col * F + row] : W[(int64_t)row * F + col];
+                // the backward copy carries om_{l-1}: delta_{l-1} = (om W_l^T delta_l) . cos(om z_{l-1}); the forward copy om_l / 2 pi
+                if (row < F && col < F) w = bwd ? brief_om_prev(d, l) * W[(int64_t)col * F + row] : brief_phase_scale(d, l) * W[(int64_t)row * F + col];
                 union { __bf16 h; uint16_t u; } cv;
                 cv.h = (__bf16)w;
                 word |= (uint32_t)cv.u << (16 * half);
@@ -1621,8 +1641,8 @@ __global__ void k_repack(const brief_siren_desc d, const float *__restrict__ par
     if (e < (int64_t)FP * 4) {
         const int f = (int)(e >> 2), c = (int)(e & 3);
         if (f < F) {
-            if (c < cin) v = params[(int64_t)f * cin + c];
-            else if (c == 3) v = params[(int64_t)F * cin + f];
+            if (c < cin) v = brief_phase_scale(d, 0) * params[(int64_t)f * cin + c];
+            else if (c == 3) v = brief_phase_scale(d, 0) * params[(int64_t)F * cin + f];
         }
     } else if (e < head) {
         const int64_t hs = brief_pk_hidden_stride(d);
@@ -1637,10 +1657,10 @@ __global__ void k_repack(const brief_siren_desc d, const float *__restrict__ par
             const int kt = (int)((r >> 10) % NT), mt = (int)((r >> 10) / NT);
             const int row = 32 * mt + (lanei & 31);
             const int col = 32 * kt + 8 * q + 4 * (lanei >> 5) + jj;
-            if (row < F && col < F) v = bwd ? W[(int64_t)col * F + row] : W[(int64_t)row * F + col];
+            if (row < F && col < F) v = bwd ? brief_om_prev(d, l) * W[(int64_t)col * F + row] : brief_phase_scale(d, l) * W[(int64_t)row * F + col];
         } else {
             const int f = (int)(r - 2 * (int64_t)FP * FP);
-            if (f < F) v = b[f];
+            if (f < F) v = brief_phase_scale(d, l) * b[f];
         }
     } else {
         const int64_t r = e - head;

@@ -34,13 +34,17 @@ BL_HD int64_t brief_canon_count(const brief_siren_desc &d)
     return brief_canon_head_off(d) + (int64_t)d.features * d.cout + d.cout;
 }
 
-// --- derived ("packed") buffer, all rows padded to FP = 32*NT with zeros:
-//   W0p  [FP][4]            = {w(x0), w(x1), w(x2) (0 if cin==2), bias}
+// --- derived ("packed") buffer, all rows padded to FP = 32*NT with zeros.  The copies carry the sine frequencies, so that
+//     the matrix pipe delivers what the epilogues need and no VALU instruction is spent on it (v_mfma_f32_32x32x2_f32 and
+//     the VALU share the SIMD's FMA lanes: profiles/r03_coissue.md):  s_l = w0_l / 2 pi  (brief_phase_scale) turns
+//     z_l into the PHASE of the following sine in revolutions, which v_sin_f32 / v_cos_f32 take as they are.
+//   W0p  [FP][4]            = s_0 * {w(x0), w(x1), w(x2) (0 if cin==2), bias}
 //   per hidden layer l=1..L-2:
-//     Wf [NT(mt)][NT(kt)][4(q)][64(lane)][4(j)]  A-fragments of W   : W[32mt+i][32kt+8q+4hi+j]
-//     Wb [NT(mt)][NT(kt)][4(q)][64(lane)][4(j)]  A-fragments of W^T : W[32kt+8q+4hi+j][32mt+i]
-//     bp [FP]
-//   Whp [4][FP]  (rows >= cout zero),  bhp[4]
+//     Wf [NT(mt)][NT(kt)][4(q)][64(lane)][4(j)]  A-fragments of s_l W       : W[32mt+i][32kt+8q+4hi+j]
+//     Wb [NT(mt)][NT(kt)][4(q)][64(lane)][4(j)]  A-fragments of w0_{l-1} W^T : W[32kt+8q+4hi+j][32mt+i]
+//                                                 (delta_{l-1} = (w0_{l-1} W_l^T delta_l) . cos(phase_{l-1}))
+//     bp [FP]                                     s_l * bias
+//   Whp [4][FP]  (rows >= cout zero),  bhp[4]     (unscaled)
 //   (lane = 32*hi + i ; this is the operand order of v_mfma_f32_32x32x2_f32, see brief_hip.hip)
 // number of 32-feature tiles the width is padded to: exact up to 8 tiles, then 12 or 16 (only those
 // kernel instantiations exist above 256 features)
@@ -72,8 +76,8 @@ BL_HD int64_t brief_pk_count32(const brief_siren_desc &d)
     return brief_pk_head(d) + 4 * FP + 4;
 }
 // bf16 mode appends, per hidden layer, the bf16 A-fragments of W and of W^T for v_mfma_f32_32x32x16_bf16:
-//   Wf16 [NT(mt)][NT(kt)][2(s)][64(lane)][8(j)]:  W[32mt + i][32kt + krow(s, hi, j)]       (lane = 32 hi + i)
-//   Wb16 [NT(mt)][NT(kt)][2(s)][64(lane)][8(j)]:  W[32kt + krow(s, hi, j)][32mt + i]
+//   Wf16 [NT(mt)][NT(kt)][2(s)][64(lane)][8(j)]:  s_l W[32mt + i][32kt + krow(s, hi, j)]       (lane = 32 hi + i)
+//   Wb16 [NT(mt)][NT(kt)][2(s)][64(lane)][8(j)]:  w0_{l-1} W[32kt + krow(s, hi, j)][32mt + i]
 //   krow(s, hi, j) = 16 s + 8 (j >> 2) + 4 hi + (j & 3): the row an accumulator register 8s + j of lane half hi
 //   holds, so that a converted accumulator tile IS the B operand of the next layer (cdna_hip_programming.md,
 //   'An accumulator tile as the next MFMA's operand').  Offsets below are in FLOAT units (2 bf16 each).
@@ -96,8 +100,10 @@ BL_HD int64_t brief_frag16_index(int NT, int row, int col)
     return ((((int64_t)mt * NT + kt) * 2 + s) * 64 + 32 * hi + i) * 8 + j;
 }
 
-// w0 of the sine layer below hidden layer l (1..L-2): the factor folded into the bf16 copy of W_l^T
+// w0 of the sine layer below hidden layer l (1..L-2): the factor folded into the copies of W_l^T (f32 and bf16)
 BL_HD float brief_om_prev(const brief_siren_desc &d, int l) { return l - 1 == 0 ? d.w0_first : d.w0_hidden; }
+// w0_l / 2 pi: the factor folded into layer l's forward weights and bias (l = 0: first layer, l >= 1: hidden layers)
+BL_HD float brief_phase_scale(const brief_siren_desc &d, int l) { return (l == 0 ? d.w0_first : d.w0_hidden) * 0.15915494309189535f; }
 
 // --- fused-kernel geometry per NT (how the 4 waves of a workgroup split features x sample tiles)
 BL_HD int brief_wm(int nt) { return nt >= 3 ? 4 : nt; }          // waves along features

@@ -61,9 +61,16 @@ def test_forward_shapes_vs_oracle(L, F, cin, cout, n):
     assert relerr(y, O.forward(d, p, x)) < 2e-5
 
 
-def _check_grads(m, d, grads_ref, tol=1e-4):
+def _check_grads(m, d, grads_ref, tol=1e-4, grads_ref64=None):
+    """every gradient tensor within tol of its max-abs.  grads_ref64 (the oracle's float64 instantiation on the same
+    inputs) widens the band to 3x the largest distance between the oracle's OWN f32 and f64 answers over the net's tensors:
+    where the reference arithmetic is that far from the exact gradient (deep one- or two-wide nets multiply every rounding
+    error by w0 per layer), a tighter agreement between two f32 evaluation orders is not a property of either."""
     gw, gb = O.unpack_params(d, grads_ref)
     mw, mb = O.unpack_params(d, m.grads.cpu().numpy())
+    if grads_ref64 is not None:
+        w64, b64 = O.unpack_params(d, grads_ref64)
+        tol = max(tol, 3.0 * max(max(relerr(gw[l], w64[l]), relerr(gb[l], b64[l])) for l in range(d.layers)))
     for l in range(d.layers):
         assert relerr(mw[l], gw[l]) < tol, ("weight", l)
         assert relerr(mb[l], gb[l]) < tol, ("bias", l)
@@ -210,7 +217,8 @@ def test_seeded_random_shapes_vs_oracle(L, F, cin, cout, n, oa, loss, use_w, thr
     g1 = m.grads.clone()
     lo, go, _, _ = O.loss_grad(d, p, x, y, w if use_w else np.ones_like(y), 1 if loss == "datasmoothl1" else 0, thr, beta)
     assert abs(l1.item() - lo) <= 1e-5 * abs(lo) + 1e-9
-    _check_grads(m, d, go)
+    _, go64, _, _ = O.loss_grad(d, p, x, y, w if use_w else np.ones_like(y), 1 if loss == "datasmoothl1" else 0, thr, beta, f64=True)
+    _check_grads(m, d, go, grads_ref64=go64)
     l2, _ = m.train_step(n, yt, coords=xt, weights=wt, loss=loss, thr=thr, beta=beta)
     assert torch.equal(g1, m.grads) and l1.item() == l2.item()
 
@@ -335,20 +343,29 @@ def _fit_half_golden(golden, precision):
 def test_end_of_fit_3000_steps_golden(golden):
     """a 3000-step fit of a 128-wide net to its end against the reference's own runs.  The band is the reference's OWN
     noise on this case, measured: tests/golden/half.npz (4 CPU threads) and half_self.npz (1 thread: only the reduction
-    order of its GEMMs changes) are 2e-7 apart at step 50, 9e-5 at step 100, 6e-4 at step 200, 1.4e-2 at step 500 and
-    0.16 dB apart in final PSNR (56.26 / 56.42 dB); the CPU oracle sits 8e-4 from the 4-thread trace at step 200."""
+    order of its GEMMs changes) are 2e-7 apart at step 50, 9e-5 at step 100, 6e-4 at step 200, 1.4e-2 at step 500; the CPU
+    oracle sits 8e-4 from the 4-thread trace at step 200.  End of fit: the loss of this case oscillates between 1.5 and
+    3.0 over its last 200 steps, so the PSNR AT step 3000 is one sample of that oscillation: changing ONE initial weight
+    by one ulp moves it over 55.18 ... 56.28 dB on one build and 54.15 ... 56.27 dB on another (tools/endfit_spread.py,
+    profiles/r03_endfit_spread.md: std 0.3-0.7 dB; the reference's two runs: 56.26 / 56.42).  What IS stable is the
+    envelope: the minimum of the last 200 losses stays within 1.536 ... 1.617 over all those runs (reference 1.550 /
+    1.504), so the quality of the fit is pinned on the envelope and the PSNR at the last step gets the measured noise."""
     g, losses, psnr = _fit_half_golden(golden, "fp32")
     g2 = golden("half_self")
     ref, ref2 = g["f32_losses"], g2["f32_losses"]
     err = np.abs(losses - ref) / ref
     self_err = np.abs(ref2 - ref) / ref
     p1, p2 = float(g["f32_psnr"][0]), float(g2["f32_psnr"][0])
+    env, env_ref = losses[-200:].min(), 0.5 * (ref[-200:].min() + ref2[-200:].min())
+    med, med_ref = np.median(losses[-200:]), 0.5 * (np.median(ref[-200:]) + np.median(ref2[-200:]))
     print("3000-step fit: trace error through step 50 / 100 / 200: %.1e / %.1e / %.1e (reference vs itself: %.1e / %.1e / %.1e); "
-          "PSNR %.3f dB (reference %.3f and %.3f dB)" % (err[:50].max(), err[:100].max(), err[:200].max(), self_err[:50].max(),
-                                                         self_err[:100].max(), self_err[:200].max(), psnr, p1, p2))
+          "last-200 loss min %.4f median %.4f (reference %.4f / %.4f); PSNR %.3f dB (reference %.3f and %.3f dB)"
+          % (err[:50].max(), err[:100].max(), err[:200].max(), self_err[:50].max(), self_err[:100].max(), self_err[:200].max(),
+             env, med, env_ref, med_ref, psnr, p1, p2))
     assert err[:50].max() < 1e-5
     assert err[:100].max() < 3e-4 and err[:200].max() < 2e-3          # ~3x the reference's own divergence at those steps
-    assert abs(psnr - 0.5 * (p1 + p2)) < 2.5 * abs(p1 - p2)            # 0.4 dB around the reference's two runs (measured 0.29)
+    assert abs(env - env_ref) < 0.08 * env_ref and abs(med - med_ref) < 0.12 * med_ref     # the envelope of the end of the fit
+    assert abs(psnr - 0.5 * (p1 + p2)) < 2.5                           # one sample of the oscillation (see above)
 
 
 def test_decode_golden(golden):
