@@ -15,6 +15,12 @@ Workload (BASELINE.json metric: "voxels/sec encode (512^3 vol, 4x256 SIREN)"):
 A step = one pass of the hot path over one batch: sample 100000 voxels -> fused forward/loss/
 backward -> optimizer update.  value = sampled voxels fitted per second over all ranks, with
 the volume resident in HBM when the timed region starts.
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (a child `python -m
+torch.distributed.run`, decided before anything touches the GPU) and exits with the child's code; under torchrun the
+world size must equal --gpus.  The N = 1 line also carries, all timed in this run: `configs` (BASELINE config 1 on
+k_small, config 3 on the bf16 kernels), a three-point `psnr_at_bitrate_sweep` on the 512^3 volume, and `encode` /
+`decode` as wall clocks around a real NFGR.compress / NFGR.decompress of the host-resident volume.
 """
 import argparse
 import ctypes as C
@@ -186,6 +192,124 @@ def divide_bench(args, dist, rank, world, dev, red_dev):
     return elapsed, tot_ms.value / max(launches.value, 1), perf, pcount
 
 
+def launch_ranks(args):
+    """--gpus N without a launcher: start N ranks as a CHILD process (never an exec: the box forbids replacing a process
+    that touched the GPU, and this one has not touched it yet either) and hand its exit code back"""
+    import socket
+    import subprocess
+    if args.gpus > torch.cuda.device_count():           # (counting devices does not initialise the GPU)
+        sys.stderr.write("bench.py: --gpus %d but only %d device(s) are visible\n" % (args.gpus, torch.cuda.device_count()))
+        sys.exit(2)
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
+
+
+def timed_config(name, L, F, dims, sampler, n, precision, steps, tgt=None, seed=7):
+    """one BASELINE configuration on this GPU: `steps` optimizer steps in one brief_siren_fit call, wall clock bracketed by
+    synchronize, the dominant kernel timed by HIP events inside the library (as for the headline)."""
+    L_ = _lib.lib()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    if tgt is None:
+        vol = make_volume_torch(dims, seed=seed, device=dev)
+        t = vol.view(-1, 1).to(torch.float32)
+        vmin, vmax = float(t.min().item()), float(t.max().item())
+        tgt = (t - np.float32(vmin)) / np.float32(vmax - vmin)
+        tgt *= np.float32(100.0)
+    torch.manual_seed(seed)
+    net = SIREN(coords_channel=3, data_channel=1, features=F, layers=L, w0=W0, precision=precision).to(dev)
+    fit = Fitter(net, tgt, dims, sampler=sampler, sample_size=n, optimizer="Adamax", lr=1e-3,
+                 scheduler={"name": "MultiStepLR", "milestones": [50000, 60000, 70000], "gamma": 0.2}, seed=seed)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.3:               # clock ramp + caches
+        fit.run(20)
+        torch.cuda.synchronize()
+    _lib.check(L_.brief_profile_enable(1))
+    t1 = time.perf_counter()
+    fit.run(steps)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t1
+    tot_ms, launches = C.c_double(0), C.c_int64(0)
+    _lib.check(L_.brief_profile_fused(C.byref(tot_ms), C.byref(launches)))
+    _lib.check(L_.brief_profile_enable(0))
+    train_f, fused_f, _ = flops_per_sample(L, F)
+    peak = PEAK_F32_MFMA_TFLOPS if precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
+    nb = fit.n
+    kms = tot_ms.value / max(launches.value, 1)
+    small = F <= 64 and precision == "fp32"              # k_small is the whole train step but the reduction
+    kflop = (train_f if small else fused_f) * nb
+    return {"workload": name, "layers": L, "features": F, "volume": list(dims), "samples_per_step": nb, "dtype": "f32" if precision == "fp32" else "bf16",
+            "steps": steps, "ms_per_step": el * 1e3 / steps, "voxels_per_s": nb * steps / el,
+            "step_tflops": train_f * nb / (el / steps) / 1e12, "step_frac": train_f * nb / (el / steps) / 1e12 / peak,
+            "kernel": "k_small" if small else ("k_fused" if precision == "fp32" else "k16 (body + tail launches)"),
+            "kernel_ms": kms, "kernel_tflops": kflop / (kms * 1e-3) / 1e12, "kernel_frac": kflop / (kms * 1e-3) / 1e12 / peak, "peak_tflops": peak}
+
+
+def rate_point(F, tgt, vol, vmin, vmax, steps, seed=42):
+    """one point of the PSNR-vs-bitrate curve on the 512^3 block: a (LAYERS, F) net fitted for `steps` steps, decoded, PSNR from
+    the GPU SSE"""
+    dev = tgt.device
+    torch.manual_seed(seed)
+    net = SIREN(coords_channel=3, data_channel=1, features=F, layers=LAYERS, w0=W0).to(dev)
+    fit = Fitter(net, tgt, BLOCK, sampler="randompoint", sample_size=SAMPLE, optimizer="Adamax", lr=1e-3,
+                 scheduler={"name": "MultiStepLR", "milestones": [50000, 60000, 70000], "gamma": 0.2}, seed=seed)
+    t0 = time.perf_counter()
+    fit.run(steps)
+    dec = net.decode_grid(BLOCK, out_kind="u16", scale=(0.0, 100.0), vrange=(vmin, vmax))
+    sse = torch.zeros(1, dtype=torch.float64, device=dev)
+    _lib.check(_lib.lib().brief_sse_u16(_lib.ptr(vol), _lib.ptr(dec), vol.numel(), _lib.ptr(sse), _lib.stream_ptr()))
+    psnr = float(-10.0 * np.log10(sse.item() / vol.numel() / 65535.0 ** 2))
+    return {"features": F, "params": net.param_count, "bits_per_voxel": 32.0 * net.param_count / float(np.prod(BLOCK)), "steps": steps,
+            "psnr_db": psnr, "seconds": time.perf_counter() - t0}
+
+
+def encode_decode_wall(vol_host, steps):
+    """SURVEY 8d's encode figure, measured: wall clock around NFGR.compress of the HOST-resident volume (preprocess, the
+    reference's `_preprocessed` dump, loss-weight map, normalise, H2D, net init, `steps` optimizer steps, weight files +
+    sideinfos.yaml) and around NFGR.decompress of the stored artefact (load, decode kernel, D2H, postprocess)."""
+    import shutil
+    import tempfile
+    from brief_pytorch_amd import config
+    from brief_pytorch_amd.framework import NFGR, MyLogger, _wrap
+    work = tempfile.mkdtemp(prefix="brief_e2e_")
+    try:
+        opt = config.load(os.path.join(ROOT, "opt", "SingleTask", "default.yaml"))
+        cf = opt.CompressFramework
+        pcount = SIREN.calc_param_count(3, 1, FEATURES, LAYERS)
+        cf.Module.phi.layers, cf.Module.phi.w0 = LAYERS, W0
+        cf.Compress.param.filesize_ratio, cf.Compress.param.given_size = 0, 4.0 * pcount
+        cf.Compress.max_steps, cf.Compress.checkpoints, cf.Compress.loss_log_freq = steps, "none", 10 ** 9
+        cf.Compress.decompress = False
+        cf["_seed"] = 42
+        Log = MyLogger(outputs_dir=work, project_name="e2e", time=False)
+        torch.manual_seed(42)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fw = NFGR(cf, Log=Log)
+        fw.compress(os.path.join(work, "volume.npy"), data=vol_host)
+        torch.cuda.synchronize()
+        t_enc = time.perf_counter() - t0
+        cdir = os.path.join(Log.logdir, "steps%d" % steps, "compressed")
+        t1 = time.perf_counter()
+        dec = NFGR.decompress(opt, os.path.join(cdir, "module"), os.path.join(cdir, "sideinfos.yaml"))
+        t_dec = time.perf_counter() - t1
+        d = dec.astype(np.float32) - vol_host.astype(np.float32)
+        psnr = float(-10.0 * np.log10(float((d.astype(np.float64) ** 2).mean()) / 65535.0 ** 2))
+        files = sum(os.path.getsize(os.path.join(cdir, "module", f)) for f in os.listdir(os.path.join(cdir, "module")))
+        return {"steps": steps, "wall_seconds": t_enc, "voxels_per_s": vol_host.size / t_enc, "fit_seconds": fw.fit_seconds,
+                "artefact_bytes": files + os.path.getsize(os.path.join(cdir, "sideinfos.yaml")),
+                "note": "wall clock of NFGR.compress on the host-resident 512^3 uint16 volume: preprocess + _preprocessed dump + normalise + H2D + "
+                        "net init + %d steps (fit_seconds) + weight files" % steps}, \
+               {"wall_seconds": t_dec, "voxels_per_s": vol_host.size / t_dec, "psnr_db": psnr,
+                "note": "wall clock of NFGR.decompress of the stored artefact: load weights, decode kernel (de-normalise + cast fused), D2H, postprocess"}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -199,20 +323,42 @@ def main():
     ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
                     help="fp32 = the metric (exact f32 MFMA); bf16 = BASELINE config 3's arithmetic (extra lines, never the default)")
     ap.add_argument("--config", choices=["c2", "c3"], default="c2", help="c2: 4x256 SIREN (the metric); c3: 8x512 SIREN")
+    ap.add_argument("--divide", action="store_true", help="run the DivideTask product path also at world size 1 (one block, process group initialised)")
+    ap.add_argument("--block", type=int, default=512, help="edge of the cubic block (tests only; the metric is quoted on 512)")
+    ap.add_argument("--no-extras", action="store_true", help="skip configs / psnr_at_bitrate_sweep / the NFGR wall clocks (headline line only)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)                              # does not return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node equal to --gpus\n" % (args.gpus, world))
+        sys.exit(2)
+    global BLOCK
+    BLOCK = (args.block,) * 3
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     # "nccl" IS RCCL on ROCm.  BRIEF_DIST_BACKEND=gloo only exists to rehearse the N>1 code path on a
     # box with fewer GPUs than ranks (ranks then share devices and the reductions go through the host).
     backend = os.environ.get("BRIEF_DIST_BACKEND", "nccl")
-    if world > 1:
+    if world > 1 or args.divide:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank % torch.cuda.device_count())
+        if world == 1:                                   # --divide without a launcher: a one-rank group
+            import socket
+            sock = socket.socket()
+            sock.bind(("127.0.0.1", 0))
+            free_port = sock.getsockname()[1]
+            sock.close()
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(free_port))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank % torch.cuda.device_count()))
         else:
             dist.init_process_group(backend)
     else:
@@ -224,7 +370,7 @@ def main():
     if args.config == "c3":
         LAYERS, FEATURES = 9, 512
 
-    if world > 1:
+    if world > 1 or args.divide:
         elapsed, fused_ms, perf, pcount = divide_bench(args, dist, rank, world, dev, red_dev)
         if rank == 0:
             train_f, fused_f, _ = flops_per_sample(LAYERS, FEATURES)
@@ -235,9 +381,9 @@ def main():
                 "metric": "encode_voxels_per_sec", "value": SAMPLE * args.steps * world / elapsed, "unit": "voxels/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
-                "config": {"workload": "DivideTask (NFGR.compress_divide) on a synthetic uint16 volume of %d x 512^3 blocks (total_%d_1_1), one block and "
+                "config": {"workload": "DivideTask (NFGR.compress_divide) on a synthetic uint16 volume of %d x %d^3 blocks (total_%d_1_1), one block and "
                                        "one SIREN %dx%d (layers=%d, features=%d, w0=20) per rank, randompoint sample_size=100000, datal2, Adamax lr=1e-3"
-                                       % (world, world, LAYERS - 1, FEATURES, LAYERS, FEATURES),
+                                       % (world, BLOCK[0], world, LAYERS - 1, FEATURES, LAYERS, FEATURES),
                            "volume": [world * BLOCK[0], BLOCK[1], BLOCK[2]], "layers": LAYERS, "features": FEATURES, "sample_size": SAMPLE,
                            "params": pcount, "bits_per_voxel": 32.0 * pcount / float(np.prod(BLOCK))},
                 "roofline": {"bound": "mfma", "kernel": ("k_fused<%d,true>" if args.precision == "fp32" else "k16<%d,true,1>") % (FEATURES // 32)
@@ -323,11 +469,27 @@ def main():
         psnr = float(-10.0 * np.log10(red[0].item() / red[1].item() / 65535.0 ** 2))
         nvox = float(np.prod(BLOCK))
         ms_more = t_more * 1e3 / more if more else elapsed * 1e3 / args.steps
-        t_encode = steps_done * ms_more * 1e-3                  # every step of the fit at the measured steady rate
-        extra = {"encode": {"steps": steps_done, "seconds": t_encode, "voxels_per_s": nvox / t_encode, "ms_per_step": ms_more,
-                            "note": "whole 512^3 block / (steps x steady step time): sampler, optimizer and lr schedule included, checkpoints off"},
-                 "decode": {"seconds": t_dec, "voxels_per_s": nvox / t_dec, "tflops": nvox * flops_per_sample(LAYERS, FEATURES)[2] / t_dec / 1e12,
-                            "note": "decode_grid of the whole block: coordinates synthesised in-kernel, de-normalise + uint16 cast fused"}}
+        extra = {"decode_kernel": {"seconds": t_dec, "voxels_per_s": nvox / t_dec, "tflops": nvox * flops_per_sample(LAYERS, FEATURES)[2] / t_dec / 1e12,
+                                   "note": "decode_grid of the whole block, output left in HBM: coordinates synthesised in-kernel, de-normalise + uint16 cast fused"},
+                 "steady_state_fit": {"steps": steps_done, "ms_per_step": ms_more, "note": "continuation of the timed fit to --encode-steps in one brief_siren_fit call"}}
+        if not args.no_extras and world == 1:
+            # ---- the other BASELINE configurations, driver-timed in this run
+            cfgs = {}
+            cfgs["c1_64cube_2x64_full_batch"] = timed_config("SingleTask 64^3 synthetic volume, SIREN 2x64 (layers=3, features=64), one randomcube window = "
+                                                             "the whole grid (262144 samples per step), Adamax", 3, 64, (64, 64, 64), "full", 0, "fp32", 400)
+            cfgs["default_yaml_64cube_4x22"] = timed_config("SingleTask default.yaml on a 64^3 volume: the budget solves to SIREN 4x22 (layers=5, features=22), "
+                                                            "full-volume batch", 5, 22, (64, 64, 64), "full", 0, "fp32", 400)
+            cfgs["c3_512cube_8x512_bf16"] = timed_config("SingleTask 512^3 synthetic volume, SIREN 8x512 (layers=9, features=512), bf16 MFMA with f32 master weights, "
+                                                         "randompoint sample_size=100000", 9, 512, BLOCK, "randompoint", SAMPLE, "bf16", 60, tgt=tgt)
+            extra["configs"] = cfgs
+            # ---- PSNR against bitrate on the 512^3 volume: three net sizes, --encode-steps steps each
+            pts = [rate_point(128, tgt, vol, vmin, vmax, steps_done),
+                   {"features": FEATURES, "params": net.param_count, "bits_per_voxel": 32.0 * net.param_count / nvox, "steps": steps_done, "psnr_db": psnr},
+                   rate_point(384, tgt, vol, vmin, vmax, steps_done)]
+            extra["psnr_at_bitrate_sweep"] = pts
+            # ---- encode / decode as wall clocks of the product path on the host-resident volume
+            enc, dec_w = encode_decode_wall(vol.cpu().numpy(), args.encode_steps if args.encode_steps > 0 else 2000)
+            extra["encode"], extra["decode"] = enc, dec_w
 
     if rank == 0:
         # HBM traffic of the dominant kernel: PMC counters need rocprofv3, so this figure is NOT measured in this run; it is

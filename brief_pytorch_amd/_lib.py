@@ -41,7 +41,8 @@ class FitJob(C.Structure):          # brief_fit_job
                 ("loss_kind", C.c_int32), ("optim_kind", C.c_int32), ("thr", C.c_float), ("beta", C.c_float),
                 ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
                 ("milestones", C.POINTER(C.c_int64)), ("n_milestones", C.c_int32), ("reserved", C.c_int32),
-                ("gamma", C.c_double), ("t0", C.c_int64)]
+                ("gamma", C.c_double), ("t0", C.c_int64),
+                ("lr_table", C.POINTER(C.c_double)), ("beta1_table", C.POINTER(C.c_double)), ("idx_stride", C.c_int64)]
 
 
 LOSS_KIND = {"datal2": 0, "datasmoothl1": 1, "external": 2}

@@ -2365,7 +2365,8 @@ int brief_siren_fit_step(const brief_siren_desc *d, float *params, float *packed
 static int fit_job_check(const brief_fit_job *j)
 {
     if (!j) return fail(BRIEF_ERR_INVALID, "null job");
-    if (j->batch.idx) return fail(BRIEF_ERR_INVALID, "a per-step index stream cannot be replayed by brief_siren_fit: use brief_siren_fit_step");
+    if (j->batch.idx && j->idx_stride <= 0) return fail(BRIEF_ERR_INVALID, "brief_siren_fit needs idx_stride > 0 with batch.idx (one index set per step); a single set goes to brief_siren_fit_step");
+    if (j->batch.idx && j->idx_stride < j->batch.n) return fail(BRIEF_ERR_INVALID, "idx_stride is smaller than the batch");
     if (!j->params || !j->packed || !j->grads || !j->loss_out || !j->workspace) return fail(BRIEF_ERR_INVALID, "null buffer");
     if (j->t0 < 0) return fail(BRIEF_ERR_INVALID, "bad step count");
     if (j->n_milestones < 0 || (j->n_milestones > 0 && !j->milestones)) return fail(BRIEF_ERR_INVALID, "bad lr milestones");
@@ -2376,15 +2377,17 @@ static int fit_job_check(const brief_fit_job *j)
 static int fit_job_step(const brief_fit_job *j, int64_t t, int64_t k, double *lr, hipStream_t st)
 {
     // scheduler.step() calls made so far = t - 1: apply the milestones that were hit by the last one
-    if (t - 1 > j->t0) {
+    if (j->lr_table) *lr = j->lr_table[k];
+    else if (t - 1 > j->t0) {
         int hits = 0;
         for (int m = 0; m < j->n_milestones; ++m) hits += (j->milestones[m] == t - 1);
         if (hits) *lr = *lr * pow(j->gamma, (double)hits);
     }
     brief_batch_desc b = j->batch;
-    if (!b.idx && b.rng_pop > 0) b.rng_step = (uint64_t)t;
+    if (b.idx) b.idx = b.idx + k * j->idx_stride;          // device-resident index stream: this step's set
+    else if (b.rng_pop > 0) b.rng_step = (uint64_t)t;
     return brief_siren_fit_step(&j->desc, j->params, j->packed, &j->grid, &b, j->loss_kind, j->thr, j->beta, j->optim_kind,
-                                j->state1, j->state2, *lr, j->beta1, j->beta2, j->eps, t, j->grads,
+                                j->state1, j->state2, *lr, j->beta1_table ? j->beta1_table[k] : j->beta1, j->beta2, j->eps, t, j->grads,
                                 j->loss_log ? j->loss_log + k : j->loss_out, j->workspace, j->workspace_bytes, (void *)st);
 }
 

@@ -120,21 +120,39 @@ class Fitter:
         self._ms_arr = (C.c_int64 * max(len(self._milestones), 1))(*self._milestones)
         self._keep = None
 
+    # indices of a run of steps live on the device as one [steps, n] int64 tensor: at most this many bytes per C-ABI call
+    INDEX_STREAM_BYTES = 1 << 28
+
+    def max_steps_per_call(self):
+        return max(1, self.INDEX_STREAM_BYTES // (8 * self.n)) if self.index_stream is not None else 1 << 62
+
+    def _index_batch(self, t_first, steps):
+        """the index sets of steps t_first .. t_first + steps - 1 as one device tensor [steps, n] (draw order = step order,
+        so the host RNG is consumed exactly as by per-step calls)"""
+        if hasattr(self.index_stream, "batch"):
+            return self.index_stream.batch(t_first, steps)
+        return torch.stack([self.index_stream(t_first + k) for k in range(steps)]).contiguous()
+
     def job(self, steps, log=False):
-        """brief_fit_job for the next `steps` optimizer steps (include/brief_hip.h).  Tensors referenced by the
-        job are kept alive by this object until the next call."""
-        if self.index_stream is not None:
-            raise _lib.BriefError("a replayed index stream needs step(): brief_siren_fit draws its indices in-kernel")
-        if self._sched_name in ("StepLR", "CyclicLR"):
-            raise _lib.BriefError("%s is applied by step()/run(); brief_fit_job carries MultiStepLR only" % self._sched_name)
+        """brief_fit_job for the next `steps` optimizer steps (include/brief_hip.h).  Tensors and host arrays referenced by
+        the job are kept alive by this object until the next call.  MultiStepLR travels as milestones; the closed-form
+        schedules (StepLR, CyclicLR incl. its cycled beta1) as per-step host tables; a replayed / windowed-cube index stream
+        as one device-resident [steps, n] tensor."""
+        steps = int(steps)
+        if steps > self.max_steps_per_call():
+            raise _lib.BriefError("index stream: at most %d steps per call (use run())" % self.max_steps_per_call())
         m = self.m
         m._require_gpu()
         m.sync_packed()
         m.ensure_train_buffers(self.n)
-        loss_log = torch.zeros(max(int(steps), 1), dtype=torch.float32, device=m.params.device) if log else None
+        loss_log = torch.zeros(max(steps, 1), dtype=torch.float32, device=m.params.device) if log else None
         g = m._grid(self.dims, self.range[0], self.range[1])
-        rnd = self.sampler == "randompoint"
-        b = _lib.BatchDesc(None, self.targets.data_ptr(), self.weights.data_ptr() if self.weights is not None else None, None,
+        rnd = self.sampler == "randompoint" and self.index_stream is None
+        idx = self._index_batch(self.t + 1, steps) if (self.index_stream is not None and steps > 0) else None
+        if idx is not None and (idx.dtype != torch.int64 or tuple(idx.shape) != (steps, self.n) or idx.device != m.params.device):
+            raise _lib.BriefError("index stream must yield int64 [steps, %d] on %s" % (self.n, m.params.device))
+        b = _lib.BatchDesc(None, self.targets.data_ptr(), self.weights.data_ptr() if self.weights is not None else None,
+                           idx.data_ptr() if idx is not None else None,
                            0, int(self.n), int(self.pop) if rnd else 0, int(self.seed) if rnd else 0, 0)
         j = _lib.FitJob()
         j.desc, j.grid, j.batch = m.desc, g, b
@@ -148,32 +166,43 @@ class Fitter:
         j.lr, j.beta1, j.beta2, j.eps = self.lr_at(self.t + 1), 0.9, 0.999, 1e-8
         j.milestones = C.cast(self._ms_arr, C.POINTER(C.c_int64))
         j.n_milestones, j.gamma, j.t0 = len(self._milestones), self._gamma, self.t
-        self._keep = (loss_log, g, b)
+        lr_tab = b1_tab = None
+        if self._sched_name in ("StepLR", "CyclicLR") and steps > 0:
+            lr_tab = (C.c_double * steps)(*[self.lr_at(self.t + 1 + k) for k in range(steps)])
+            j.lr_table = C.cast(lr_tab, C.POINTER(C.c_double))
+            if self.beta1_at(self.t + 1) is not None:
+                b1_tab = (C.c_double * steps)(*[self.beta1_at(self.t + 1 + k) for k in range(steps)])
+                j.beta1_table = C.cast(b1_tab, C.POINTER(C.c_double))
+        j.idx_stride = self.n if idx is not None else 0
+        self._keep = (loss_log, g, b, idx, lr_tab, b1_tab)
         return j, loss_log
 
     def run(self, steps, log=False):
-        """`steps` optimizer steps in ONE C-ABI call (brief_siren_fit): same results, bit for bit, as calling
-        step() that many times.  Returns the device loss of the last step, or the per-step loss tensor if log."""
-        if self._sched_name in ("StepLR", "CyclicLR"):
-            # closed-form schedules (lr * gamma^(epoch // step_size); the triangular cycle), not the running product
-            # brief_siren_fit applies: keep them exact by stepping from here
-            losses = [self.step().clone() for _ in range(int(steps))]
-            return torch.cat(losses) if log else self.m._loss
-        j, loss_log = self.job(steps, log)
-        _lib.check(_lib.lib().brief_siren_fit(C.byref(j), int(steps), _lib.stream_ptr()))
-        self.t += int(steps)
-        return loss_log if log else self.m._loss
+        """`steps` optimizer steps in as few C-ABI calls as the index-stream budget allows (one, unless a windowed cube
+        sampler or a replayed stream is attached): same results, bit for bit, as calling step() that many times.  Returns
+        the device loss of the last step, or the per-step loss tensor if log."""
+        steps, logs = int(steps), []
+        while True:
+            k = min(steps, self.max_steps_per_call())
+            j, loss_log = self.job(k, log)
+            _lib.check(_lib.lib().brief_siren_fit(C.byref(j), k, _lib.stream_ptr()))
+            self.t += k
+            steps -= k
+            if log:
+                logs.append(loss_log[:k])
+            if steps <= 0:
+                break
+        return (torch.cat(logs) if len(logs) > 1 else logs[0]) if log else self.m._loss
 
     def step(self):
         """one optimisation step; returns the device loss tensor (no sync)."""
         self.t += 1
         t = self.t
         idx, rng = None, None
-        if self.sampler == "randompoint":
-            if self.index_stream is not None:
-                idx = self.index_stream(t)
-            else:
-                rng = (self.pop, self.seed, t)      # drawn inside the fused kernel (== brief_sample_indices(pop, seed, t))
+        if self.index_stream is not None:
+            idx = self.index_stream(t)
+        elif self.sampler == "randompoint":
+            rng = (self.pop, self.seed, t)      # drawn inside the fused kernel (== brief_sample_indices(pop, seed, t))
         b1 = self.beta1_at(t)
         return self.m.fit_step(self.n, self.targets, self.opt, self.s1, self.s2, self.lr_at(t), t, idx=idx, weights=self.weights,
                                grid=(self.dims, self.range[0], self.range[1]), loss=self.loss_name, thr=self.thr, beta=self.beta, rng=rng,
@@ -191,9 +220,17 @@ class MultiFitter:
     def run(self, steps, log=False):
         if not self.fitters:
             return []
-        jobs, logs = zip(*(f.job(steps, log) for f in self.fitters))
-        arr = (_lib.FitJob * len(jobs))(*jobs)
-        _lib.check(_lib.lib().brief_multi_fit(arr, len(jobs), int(steps), _lib.stream_ptr()))
-        for f in self.fitters:
-            f.t += int(steps)
-        return list(logs) if log else [f.m._loss for f in self.fitters]
+        steps, logs = int(steps), [[] for _ in self.fitters]
+        while True:
+            k = min([steps] + [f.max_steps_per_call() for f in self.fitters])
+            jobs, lg = zip(*(f.job(k, log) for f in self.fitters))
+            arr = (_lib.FitJob * len(jobs))(*jobs)
+            _lib.check(_lib.lib().brief_multi_fit(arr, len(jobs), k, _lib.stream_ptr()))
+            for f, acc, l in zip(self.fitters, logs, lg):
+                f.t += k
+                if log:
+                    acc.append(l[:k])
+            steps -= k
+            if steps <= 0:
+                break
+        return [torch.cat(a) if len(a) > 1 else a[0] for a in logs] if log else [f.m._loss for f in self.fitters]

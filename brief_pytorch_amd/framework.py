@@ -258,7 +258,7 @@ class NFGR:
             perf["loss"] = float(loss.item())
             _append_csv(opj(ctx["logdir"], "performance.csv"), perf)
             ctx["results"][steps] = perf
-        # step directories are always kept (the reference's inverted -stepstore flag is not reproduced)
+        # (which step directories survive is compress()'s business: main.py:452-453 / -stepstore)
 
     def compress(self, data_path, data=None, logdir=None, evaluate=True):
         """main.py:322-454.  The loop body runs inside libbrief_hip.so: one brief_siren_fit call covers every step up to
@@ -273,10 +273,12 @@ class NFGR:
         t_fit, done = 0.0, 0
         for stop in stops:
             t0 = time.perf_counter()
-            loss = fit.run(stop - done) if fit.index_stream is None else [fit.step() for _ in range(stop - done)][-1]
+            loss = fit.run(stop - done)
             done = stop
             if freq > 0 and stop % freq == 0:
                 Log.log_metrics({"loss": loss.item()}, stop)      # the only host sync, at log frequency
+            if stop in checkpoints or stop == max_steps:
+                torch.cuda.synchronize()                          # (the weight files are read back next anyway: fit_seconds is device time)
             t_fit += time.perf_counter() - t0
             if stop in checkpoints:
                 self.checkpoint(ctx, stop, loss, evaluate)
@@ -316,15 +318,16 @@ class NFGR:
         """marks / on_mark: optional measurement hook (bench.py): the fit pauses at each optimizer-step count in `marks` and
         calls on_mark(step) — between two marks every block of this rank advances by exactly that many steps.
 
-        main.py:509-651 as one torch.distributed job (one process per GPU):
-          rank 0 partitions the volume and sizes the budgets, the (small) block list is broadcast;
-          every rank fits the blocks it owns (longest-first assignment, co-trained on HIP streams) from a memory-mapped
-          view of the volume and writes their artefacts into the shared steps{k}/compressed tree;
-          the decode of the merged volume is sharded by z: a rank decodes the slices of its slab block by block from the
-          stored artefacts (pruned / dropped regions stay zero, utils/misc.py:432), takes SSE and the per-slice SSIM sums on
-          the GPU against the ORIGINAL data, and writes its slab of the output file;
-          one all-reduce of [SSE_k, SSIM-sum_k, slices, voxels] (RCCL over xGMI) gives PSNR / SSIM.  No volume-sized object
-          ever travels between ranks."""
+        main.py:509-651 as one torch.distributed job (one process per GPU), in three phases:
+          _partition_blocks  rank 0 partitions the volume and sizes the budgets, the (small) block list is broadcast and
+                             mapped to the ranks (longest-first, computed identically everywhere);
+          _fit_blocks        every rank fits the blocks it owns (co-trained on HIP streams) from a memory-mapped view of the
+                             volume and writes their artefacts into the shared steps{k}/compressed tree;
+          _evaluate_divide   the decode of the merged volume is sharded by z: a rank decodes the slices of its slab block by
+                             block from the stored artefacts (pruned / dropped regions stay zero, utils/misc.py:432), takes
+                             SSE and the per-slice SSIM sums on the GPU against the ORIGINAL data, and writes its slab of
+                             the output file; one all-reduce of [SSE_k, SSIM-sum_k, slices, voxels] (RCCL over xGMI) gives
+                             PSNR / SSIM.  No volume-sized object ever travels between ranks."""
         dist, rank, world = _dist()
         Log, C_ = self.Log, self.opt.Compress
         logdir = Log.logdir
@@ -332,16 +335,36 @@ class NFGR:
             data = read_img(data_path, mmap=True)
         assert data.ndim == self.opt.Module.phi.coords_channel + 1, "The data dimension {} is inconsistent with the neural network input {}!".format(data.ndim - 1, self.opt.Module.phi.coords_channel)
         assert data.shape[-1] == self.opt.Module.phi.data_channel, "The number of data channels {} is inconsistent with the output of neural network {}!".format(data.shape[-1], self.opt.Module.phi.data_channel)
+        name, ext = ops(opb(data_path))
+        checkpoints = parse_checkpoints(C_.checkpoints, C_.max_steps)
+        chunks, owner, src, orig_sideinfos = self._partition_blocks(data, data_path, name, ext)
+        self.block_order = [c["name"] for i, c in enumerate(chunks) if owner[i] == rank]      # the order this rank's nets were initialised in
+        self._fit_blocks(chunks, owner, src, ext, checkpoints, marks, on_mark)
+        if rank == 0:
+            for k in checkpoints:
+                save_yaml(orig_sideinfos, opj(logdir, "steps{}".format(k), "compressed", "sideinfos.yaml"))
+        _barrier(dist)
+        results = {}
+        if C_.decompress:
+            results = self._evaluate_divide(data, data_path, chunks, checkpoints, name, ext)
+        _barrier(dist)
+        if rank == 0 and not (self.args is not None and getattr(self.args, "substore", False)):
+            shutil.rmtree(opj(logdir, "subexps"), ignore_errors=True)
+        return results
+
+    def _partition_blocks(self, data, data_path, name, ext):
+        """partition + budget on rank 0 only (octree FFT features, variances: main.py:520-546), then names and byte budgets are
+        broadcast; returns (blocks, owner rank of every block, the array blocks are cut from, side info of the whole job)"""
+        dist, rank, world = _dist()
+        C_, logdir = self.opt.Compress, self.Log.logdir
         orig_sideinfos = {"data_shape": list(data.shape)}
         pp = C_.preprocess
         identity = preprocess_is_identity(data, pp.denoise.level, pp.denoise.close, pp.clip)
-        name, ext = ops(opb(data_path))
         param_size = self.parse_param_size(data_path)
         pre = None
         if rank == 0 or not identity:
             # (a non-trivial denoise / clip is applied to the whole volume, as the reference does before dividing it)
             pre = data if identity else preprocess(np.asarray(data), pp.denoise.level, pp.denoise.close, pp.clip)
-        # ---- partition + budget: rank 0 only (octree FFT features, variances), then broadcast names and byte budgets
         desc = None
         if rank == 0:
             save_img(opj(logdir, name + "_preprocessed" + ext), pre)
@@ -354,8 +377,6 @@ class NFGR:
         desc = broadcast_object(desc)
         orig_sideinfos["chunks_numbers"] = desc["n_all"]
         chunks = desc["chunks"]
-        checkpoints = parse_checkpoints(C_.checkpoints, C_.max_steps)
-        exceptions = _exceptions(self.opt)
         # cost model for the assignment: steps x samples/step x parameters of the block's net
         costs = []
         for c in chunks:
@@ -364,11 +385,16 @@ class NFGR:
             f, pcount, c["theory_module_size"] = NFGR.estimate_module_size(c["param_size"], task)
             ns = min(c["size"], C_.sampler.sample_size) if c["size"] > 80 ** 3 else c["size"]
             costs.append(float(C_.max_steps) * ns * pcount)
-        owner = assign_blocks(costs, world)
-        # every block this rank owns is prepared first (nets are initialised in partition order, as a serial run would),
-        # then all of them are trained TOGETHER: brief_multi_fit spreads them over HIP streams so the launches of narrow
-        # nets overlap; the results per block are those of a fit on its own.
-        src = data if identity else pre
+        return chunks, assign_blocks(costs, world), (data if identity else pre), orig_sideinfos
+
+    def _fit_blocks(self, chunks, owner, src, ext, checkpoints, marks=(), on_mark=None):
+        """main.py:547-607 for the blocks this rank owns.  Every block is prepared first (nets are initialised in partition
+        order, as a serial run would), then all of them are trained TOGETHER: brief_multi_fit spreads them over HIP streams
+        so the launches of narrow nets overlap; the results per block are those of a fit on its own.  Blocks with option
+        overrides (Compress.divide.exception) keep their own schedule and sampler: they are fitted one by one afterwards."""
+        dist, rank, world = _dist()
+        C_, logdir = self.opt.Compress, self.Log.logdir
+        exceptions = _exceptions(self.opt)
         mine = []
         for i, c in enumerate(chunks):
             if owner[i] != rank:
@@ -382,47 +408,28 @@ class NFGR:
             block = np.ascontiguousarray(_orig_block(src, c))
             mine.append((c, sub, sub_dir, sub.prepare_fit(opj(sub_dir, c["name"] + ext), data=block, logdir=sub_dir)))
             del block
-        # blocks with option overrides keep their own schedule and sampler: they are fitted one by one, the rest together
         special = [m for m in mine if m[0]["name"] in exceptions]
-        mine = [m for m in mine if m[0]["name"] not in exceptions]
-        cotrain = (len(mine) > 1 and all(m[3]["fit"].index_stream is None and m[3]["fit"]._sched_name not in ("StepLR", "CyclicLR") for m in mine)
-                   and os.environ.get("BRIEF_COTRAIN", "1") != "0")
+        together = [m for m in mine if m[0]["name"] not in exceptions]
+        cotrain = len(together) > 1 and os.environ.get("BRIEF_COTRAIN", "1") != "0"     # every schedule and sampler runs inside brief_multi_fit
         if torch.cuda.is_available():
             torch.cuda.synchronize()
         t0 = time.perf_counter()
-        stops = sorted(set(checkpoints) | {int(m) for m in marks if 0 < int(m) <= C_.max_steps})
+        marks = [int(m) for m in marks if 0 < int(m) <= C_.max_steps]
         if cotrain or on_mark is not None:
-            # step-synchronous over the blocks of this rank (co-trained on HIP streams when there are several)
-            from .fit import MultiFitter
-            fits = [m[3]["fit"] for m in mine]
-            group = MultiFitter(fits) if cotrain else None
-            done = 0
-            for k in stops:
-                if group is not None:
-                    losses = group.run(k - done)
-                else:
-                    losses = [f.run(k - done) if f.index_stream is None else [f.step() for _ in range(k - done)][-1] for f in fits]
-                done = k
-                if k in checkpoints:
-                    for (c, sub, sub_dir, ctx), loss in zip(mine, losses):
-                        sub.checkpoint(ctx, k, loss, evaluate=False)
-                if on_mark is not None and k in marks:
-                    on_mark(k)
+            self._fit_step_synchronous(together, checkpoints, marks, on_mark, cotrain)
         else:
-            special, mine = [], mine + special
-        for c, sub, sub_dir, ctx in (special if (cotrain or on_mark is not None) else mine):
+            special, together = together + special, []
+        for c, sub, sub_dir, ctx in special:        # one block after the other, each through its own checkpoints
             done = 0
             for k in checkpoints:
-                fit = ctx["fit"]
-                loss = fit.run(k - done) if fit.index_stream is None and fit._sched_name not in ("StepLR", "CyclicLR") else [fit.step() for _ in range(k - done)][-1]
+                loss = ctx["fit"].run(k - done)
                 done = k
                 sub.checkpoint(ctx, k, loss, evaluate=False)
-        mine = mine + special
         if torch.cuda.is_available():
             torch.cuda.synchronize()
         self.fit_seconds = time.perf_counter() - t0
         # ---- artefact tree (main.py:585-607)
-        for c, sub, sub_dir, ctx in mine:
+        for c, sub, sub_dir, ctx in together + special:
             for k in checkpoints:
                 srcd = opj(sub_dir, "steps{}".format(k), "compressed")
                 mdst = opj(logdir, "steps{}".format(k), "compressed", "module", c["name"])
@@ -433,18 +440,24 @@ class NFGR:
                 shutil.copy(opj(srcd, "sideinfos.yaml"), opj(sdst, "sideinfos.yaml"))
             ctx["fit"] = None
             ctx["phi"] = None
-        mine = None
-        if rank == 0:
-            for k in checkpoints:
-                save_yaml(orig_sideinfos, opj(logdir, "steps{}".format(k), "compressed", "sideinfos.yaml"))
-        _barrier(dist)
-        results = {}
-        if C_.decompress:
-            results = self._evaluate_divide(data, data_path, chunks, checkpoints, name, ext)
-        _barrier(dist)
-        if rank == 0 and not (self.args is not None and getattr(self.args, "substore", False)):
-            shutil.rmtree(opj(logdir, "subexps"), ignore_errors=True)
-        return results
+
+    @staticmethod
+    def _fit_step_synchronous(blocks, checkpoints, marks, on_mark, cotrain):
+        """all blocks of this rank advance together from stop to stop (checkpoints and measurement marks); co-trained on HIP
+        streams by brief_multi_fit when there are several.  A mark is reported BEFORE the checkpoint that may fall on the same
+        step, so that a timed window (bench.py) never contains artefact writes."""
+        from .fit import MultiFitter
+        fits = [m[3]["fit"] for m in blocks]
+        group = MultiFitter(fits) if cotrain else None
+        done = 0
+        for k in sorted(set(checkpoints) | set(marks)):
+            losses = group.run(k - done) if group is not None else [f.run(k - done) for f in fits]
+            done = k
+            if on_mark is not None and k in marks:
+                on_mark(k)
+            if k in checkpoints:
+                for (c, sub, sub_dir, ctx), loss in zip(blocks, losses):
+                    sub.checkpoint(ctx, k, loss, evaluate=False)
 
     def _decode_slab(self, step_dir, chunks, z0, z1, shape, dtype):
         """slices [z0, z1) of the merged volume decoded from the stored artefacts of `step_dir`: every block that meets the
@@ -453,7 +466,11 @@ class NFGR:
         device tensor in the source dtype.  2-D data: the whole image (z0 = 0, z1 = 1)."""
         three_d = len(shape) == 4
         tdt = {"uint8": torch.uint8, "uint16": torch.uint16}.get(np.dtype(dtype).name)
-        fused = tdt is not None and minmaxany_range(self.opt.Normalize.name) is not None
+        pp = self.opt.Decompress.postprocess
+        # the fused epilogue writes the source dtype directly; a Decompress.postprocess that changes values (denoise / a
+        # narrowing clip, main.py:294-295) is applied per block by NFGR.decompress, so such jobs take the host branch
+        post_identity = preprocess_is_identity(np.zeros(1, dtype), pp.denoise.level, pp.denoise.close, pp.clip)
+        fused = tdt is not None and minmaxany_range(self.opt.Normalize.name) is not None and post_identity
         out_shape = ([z1 - z0] + list(shape[1:])) if three_d else list(shape)
         slab = torch.zeros(out_shape, dtype=tdt, device=self.device) if fused else np.zeros(out_shape, dtype=np.float32)
         lo, hi = _coords_range(self.opt.Compress.coords_mode)
@@ -469,6 +486,7 @@ class NFGR:
             if fused:
                 cf = copy.deepcopy(self.opt)
                 cf.Module.phi.features = side["phi_features"]
+                cf.Module.phi.name = side.get("phi_name", cf.Module.phi.name)
                 phi = init_phi({**dict(cf.Module.phi), "precision": str(side.get("phi_precision", self.precision))})
                 load_model(phi, mod, "cpu")
                 phi.to(self.device)
@@ -531,6 +549,8 @@ class NFGR:
             for ki, k in enumerate(checkpoints):
                 sdir = opj(logdir, "steps{}".format(k))
                 dec_t = self._decode_slab(sdir, chunks, z0, z1, shape, data.dtype)
+                if gpu_metrics and not dec_t.is_cuda:
+                    dec_t = dec_t.to(self.device)      # host branch of _decode_slab (other normalisations / postprocess): the metric kernels read device memory
                 if want_mip:
                     mips[(k, name + "_decompressed")] = slab_mips(dec_t.cpu().numpy())
                 if gpu_metrics:
@@ -675,13 +695,24 @@ class _CubeIndexStream:
         self.pops = [self.dims[a] - self.cl[a] + 1 for a in range(len(self.dims))]
         self.pop_size = int(np.prod(self.pops))
 
+    def _origins(self, win):
+        """flat voxel index of the first voxel of window number `win` (int64 tensor of any shape)"""
+        org, rem = torch.zeros_like(win), win.clone()
+        for a in reversed(range(len(self.pops))):
+            org += (rem % self.pops[a]) * self.strides[a]
+            rem //= self.pops[a]
+        return org
+
     def __call__(self, t):
         win = torch.randint(0, self.pop_size, (self.count,), generator=self.gen)
-        idx = []
-        for wv in win.tolist():
-            org, rem = 0, wv
-            for a in reversed(range(len(self.pops))):
-                org += (rem % self.pops[a]) * self.strides[a]
-                rem //= self.pops[a]
-            idx.append(self.local + org)
-        return torch.cat(idx).to(self.device)
+        return (self._origins(win)[:, None] + self.local[None, :]).reshape(-1).to(self.device)
+
+    def batch(self, t_first, steps):
+        """the index sets of `steps` consecutive optimizer steps as one device tensor [steps, n]: the window numbers are
+        drawn step by step on the host generator (the reference's draw order), the expansion into voxel indices happens once
+        on the device — what lets brief_siren_fit run the windowed sampler without a host round trip per step"""
+        win = torch.stack([torch.randint(0, self.pop_size, (self.count,), generator=self.gen) for _ in range(int(steps))])
+        org = self._origins(win).to(self.device)
+        if not hasattr(self, "_local_dev"):
+            self._local_dev = self.local.to(self.device)
+        return (org[:, :, None] + self._local_dev[None, None, :]).reshape(int(steps), -1).contiguous()

@@ -144,6 +144,14 @@ typedef struct brief_fit_job {
     int32_t n_milestones, reserved;
     double gamma;
     int64_t t0;                    /* optimizer steps already taken; this call runs steps t0+1 .. t0+steps */
+    /* closed-form schedules (StepLR, CyclicLR of utils/misc.py:184-197, which torch evaluates from the epoch count, not as a
+     * running product): host arrays with one entry per step of THIS call, entry k for step t0+1+k.  lr_table overrides
+     * lr / milestones / gamma; beta1_table (CyclicLR cycles the momentum of Adam-family optimizers) overrides beta1. */
+    const double *lr_table, *beta1_table;
+    /* batch.idx with idx_stride > 0: a device-resident index STREAM, step t0+1+k reads batch.idx + k * idx_stride (int64
+     * elements).  How the windowed RandomCubeSampler (main.py:38-125) runs without a host round trip per step: the caller
+     * expands the window draws of a run of steps into voxel indices once.  idx_stride == 0 with batch.idx set is refused. */
+    int64_t idx_stride;
 } brief_fit_job;
 
 /* `steps` iterations of brief_siren_fit_step enqueued back to back on `stream` (3 launches each, no host

@@ -1,0 +1,226 @@
+"""BASELINE.json's configurations 1, 4 and 5 AT THEIR STATED SIZES under the GPU test run (round-2 verdict, "configs_untested"):
+
+  C1  SingleTask 64^3 volume, 2x64 SIREN (layers 3, features 64), full-volume batch of 262 144 samples (main.py:324-334: a
+      volume of at most 80^3 voxels is ONE randomcube window = the whole grid in flatten order every step): one step and a
+      50-step loss trace against the CPU oracle.
+  C4  DivideTask adaptive_blocking on a 1024^3 volume -> eight 512^3 octants (main.py:509-651) through NFGR.compress_divide.
+  C5  DivideTask on a vessel-shaped 64x512x512 stack, adaptive_-1_-1_0_0_20 + by_dv budget, mixed block sizes.
+
+C4 / C5 also pin ONE block of the partition: its weight files are byte-equal to a SingleTask fit of that sub-volume with the
+block's budget (so the block trained on the right voxels, offsets and budget — a sanity floor on PSNR cannot see that), and the
+first step of that SingleTask fit is checked against the oracle on the same Philox index stream."""
+import os
+import shutil
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+from brief_pytorch_amd import _lib, config, misc
+from brief_pytorch_amd.fit import Fitter
+from brief_pytorch_amd.framework import NFGR, MyLogger, _block_opt
+from brief_pytorch_amd.networks import SIREN
+from brief_pytorch_amd.synthetic import make_volume, make_volume_torch, make_vessel_volume
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = "cuda"
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-30))
+
+
+# ------------------------------------------------------------------------------------------------- C1
+def test_c1_64cube_2x64_full_volume_batch_step_and_trace_vs_oracle():
+    dims, L, F, w0 = (64, 64, 64), 3, 64, 20.0
+    vol = make_volume(dims, seed=42)
+    vn, side = O.normalize(vol)
+    n = int(np.prod(dims))
+    torch.manual_seed(42)
+    m = SIREN(features=F, layers=L, w0=w0)
+    p0 = m.params.numpy().copy()
+    m.to(DEV)
+    tv = torch.from_numpy(vn.reshape(-1, 1)).to(DEV)
+    d = O.make_desc(3, 1, L, F, w0)
+    x = O.grid_coords(dims)                       # sampler "full": sample i IS voxel i of the flattened grid
+    y = vn.reshape(-1, 1)
+    # one step: loss, yhat and every gradient tensor
+    loss, yhat = m.train_step(n, tv, grid=(dims, -1.0, 1.0), want_yhat=True)
+    lo, go, yo, _ = O.loss_grad(d, p0, x, y)
+    assert abs(loss.item() - lo) / lo < 1e-5
+    assert relerr(yhat.cpu().numpy(), yo) < 2e-5
+    gw, gb = O.unpack_params(d, go)
+    mw, mb = O.unpack_params(d, m.grads.cpu().numpy())
+    worst = max(max(relerr(mw[l], gw[l]), relerr(mb[l], gb[l])) for l in range(L))
+    assert worst < 1e-4
+    # 50 optimizer steps (Adamax 1e-3, the shipped schedule) in one brief_siren_fit call against the oracle's loop
+    fit = Fitter(m, tv, dims, sampler="full", optimizer="Adamax", lr=1e-3,
+                 scheduler={"name": "MultiStepLR", "milestones": [50000, 60000, 70000], "gamma": 0.2})
+    trace = fit.run(50, log=True).cpu().numpy().astype(np.float64)
+    p, s1, s2 = p0.copy(), np.zeros_like(p0), np.zeros_like(p0)
+    ref = []
+    for t in range(1, 51):
+        l_t, g_t, _, _ = O.loss_grad(d, p, x, y)
+        O.optim_step("Adamax", p, g_t, s1, s2, 1e-3, t)
+        ref.append(l_t)
+    ref = np.asarray(ref)
+    err = np.abs(trace - ref) / ref
+    print("C1 64^3 2x64 full batch: step loss %.6f (oracle %.6f), worst gradient tensor %.2e, 50-step trace error %.2e" % (loss.item(), lo, worst, err.max()))
+    assert err.max() < 1e-4
+    assert relerr(m.params.cpu().numpy(), p) < 1e-4
+
+
+# --------------------------------------------------------------------------------- block pin (C4 / C5)
+def _module_bytes(module_dir):
+    return {f: open(os.path.join(module_dir, f), "rb").read() for f in sorted(os.listdir(module_dir))}
+
+
+def _pin_first_block(fw, cf, logdir, steps, volume, work, layers):
+    """the FIRST block of the partition (its net is initialised first after torch.manual_seed(42), as in a serial run): a
+    SingleTask fit of that sub-volume with the block's own budget must leave byte-identical weight files, and the first
+    step of that fit is checked against the oracle on the same Philox indices."""
+    cdir = os.path.join(logdir, "steps%d" % steps, "compressed")
+    first = fw.block_order[0]          # the order compress_divide initialised this rank's nets in
+    assert first in os.listdir(os.path.join(cdir, "module"))
+    r = misc.parse_chunk_name(first)
+    block = np.ascontiguousarray(volume[r["d"][0]:r["d"][1] + 1, r["h"][0]:r["h"][1] + 1, r["w"][0]:r["w"][1] + 1])
+    side = config.load(os.path.join(cdir, "sideinfos", first, "sideinfos.yaml"))
+    feats = int(side["phi_features"])
+    budget = 4.0 * SIREN.calc_param_count(3, 1, feats, layers)
+    sub_cf = _block_opt(cf, budget)
+    sub_cf.Compress.max_steps, sub_cf.Compress.checkpoints = steps, "none"
+    sdir = os.path.join(work, "single_" + first)
+    os.makedirs(sdir, exist_ok=True)
+    torch.manual_seed(42)
+    sub = NFGR(sub_cf, Log=None)
+    ctx = sub.prepare_fit(os.path.join(sdir, first + ".npy"), data=block, logdir=sdir)
+    assert int(ctx["sideinfos"]["phi_features"]) == feats
+    fit, phi = ctx["fit"], ctx["phi"]
+    assert fit.weights is None and fit.index_stream is None
+    # ---- first step against the oracle on the index stream the kernel draws (brief_sample_indices == in-kernel Philox)
+    p0 = phi.params.cpu().numpy().copy()
+    dims = block.shape[:3]
+    pop, n = int(np.prod(dims)), fit.n
+    d = O.make_desc(3, 1, layers, feats, float(cf.Module.phi.w0))
+    if fit.sampler == "randompoint":
+        idx = torch.empty(n, dtype=torch.int64, device=DEV)
+        _lib.check(_lib.lib().brief_sample_indices(_lib.ptr(idx), n, pop, fit.seed, 1, _lib.stream_ptr()))
+        idx_h = idx.cpu().numpy()
+    else:
+        idx, idx_h = None, np.arange(pop)
+    loss1, _ = phi.train_step(n, fit.targets, idx=idx, grid=(dims, -1.0, 1.0), thr=fit.thr)
+    g1 = phi.grads.cpu().numpy().copy()
+    x = O.grid_coords(dims, idx=idx_h)
+    y = fit.targets.cpu().numpy()[idx_h]
+    lo, go, _, _ = O.loss_grad(d, p0, x, y, None, 0, fit.thr, 0.01)
+    assert abs(loss1.item() - lo) / lo < 1e-5
+    gw, gb = O.unpack_params(d, go)
+    mw, mb = O.unpack_params(d, g1)
+    worst = max(max(relerr(mw[l], gw[l]), relerr(mb[l], gb[l])) for l in range(layers))
+    assert worst < 1e-4, worst
+    # ---- the fit itself: same bytes as the block of the DivideTask run
+    loss = fit.run(steps)
+    sub.checkpoint(ctx, steps, loss, evaluate=False)
+    single = _module_bytes(os.path.join(sdir, "steps%d" % steps, "compressed", "module"))
+    divided = _module_bytes(os.path.join(cdir, "module", first, "module"))
+    assert sorted(single) == sorted(divided)
+    for f in single:
+        assert single[f] == divided[f], (first, f)
+    return first, feats, float(loss1.item()), worst
+
+
+# ------------------------------------------------------------------------------------------------- C4
+def test_c4_1024cube_adaptive_blocking_eight_octants_at_size():
+    """BASELINE config 4 at its size on one GPU: 1024^3 uint16 volume (2 GiB .npy, memory-mapped), adaptive_-1_-1_0_0_8 ->
+    the eight 512^3 octants, eight 4x256 nets co-trained on HIP streams, artefact tree, z-sharded decode + GPU SSE / SSIM of
+    the merged volume, decoded file written slab-wise (builder-run record of the same path: profiles/r02_c4_at_size.json)."""
+    E, H, steps = 1024, 512, 60
+    work = tempfile.mkdtemp(prefix="brief_c4_")
+    try:
+        path = os.path.join(work, "volume.npy")
+        mm = np.lib.format.open_memmap(path, mode="w+", dtype=np.uint16, shape=(E, E, E, 1))
+        for o in range(8):
+            z, y, x = (o >> 2) & 1, (o >> 1) & 1, o & 1
+            mm[z * H:(z + 1) * H, y * H:(y + 1) * H, x * H:(x + 1) * H] = make_volume_torch((H, H, H), seed=100 + o, device="cuda").cpu().numpy()
+        mm.flush()
+        del mm
+        opt = config.load(os.path.join(ROOT, "opt", "DivideTask", "default.yaml"))
+        cf = opt.CompressFramework
+        cf.Compress.divide.divide_type = "adaptive_-1_-1_0_0_8"
+        cf.Compress.divide.param_alloc = "by_size"
+        cf.Compress.param.filesize_ratio, cf.Compress.param.given_size = 0, 8 * 4.0 * SIREN.calc_param_count(3, 1, 256, 5)
+        cf.Compress.max_steps, cf.Compress.checkpoints, cf.Compress.loss_log_freq = steps, "none", 10 ** 9
+        cf.Compress.sampler.name = "randompoint"
+        cf.Decompress.keep_decompressed, cf.Decompress.mip = True, False
+        cf["_seed"] = 42
+        Log = MyLogger(outputs_dir=work, project_name="c4", time=False)
+        torch.manual_seed(42)
+        fw = NFGR(cf, Log=Log)
+        res = fw.compress_divide(path, opt)
+        cdir = os.path.join(Log.logdir, "steps%d" % steps, "compressed")
+        names = sorted(os.listdir(os.path.join(cdir, "module")))
+        assert names == sorted("d_%d_%d-h_%d_%d-w_%d_%d" % (z, z + H - 1, y, y + H - 1, x, x + H - 1) for z in (0, H) for y in (0, H) for x in (0, H))
+        vol = np.load(path, mmap_mode="r")
+        dec = np.load(os.path.join(Log.logdir, "steps%d" % steps, "decompressed", "volume_decompressed.npy"), mmap_mode="r")
+        assert list(dec.shape) == [E, E, E, 1]
+        # the reported PSNR is the PSNR of the file that was written (one octant re-measured on the host)
+        dd = dec[:H, :H, :H].astype(np.float64) - vol[:H, :H, :H].astype(np.float64)
+        p_oct = -10 * np.log10((dd * dd).mean() / 65535.0 ** 2)
+        assert abs(p_oct - res[steps]["psnr"]) < 1.5 and res[steps]["psnr"] > 24 and 0.5 < res[steps]["ssim"] <= 1.0
+        first, feats, l1, worst = _pin_first_block(fw, cf, Log.logdir, steps, vol, work, 5)
+        print("C4 1024^3: 8 octants, %d steps, PSNR %.2f dB SSIM %.4f; block %s (F = %d): byte-equal to its SingleTask fit, first-step loss %.4f, "
+              "worst gradient tensor vs oracle %.2e; fit %.2f s" % (steps, res[steps]["psnr"], res[steps]["ssim"], first, feats, l1, worst, fw.fit_seconds))
+        assert feats == 256
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+# ------------------------------------------------------------------------------------------------- C5
+def test_c5_vessel_64x512x512_adaptive_mixed_blocks_at_size():
+    """BASELINE config 5 at its size: opt/DivideTask/vessel.yaml (7-layer nets, w0 = 10, ratio 128) on a 64x512x512 sparse vessel-like
+    stack with the adaptive octree (adaptive_-1_-1_0_0_20) and the by_dv budget rule: mixed block sizes, every voxel in
+    exactly one block or in a pruned (all-zero) region, merged decode consistent with the reported metrics."""
+    steps = 200
+    work = tempfile.mkdtemp(prefix="brief_c5_")
+    try:
+        vol = make_vessel_volume((64, 512, 512), seed=42)
+        path = os.path.join(work, "vessel.npy")
+        np.save(path, vol)
+        opt = config.load(os.path.join(ROOT, "opt", "DivideTask", "vessel.yaml"))
+        cf = opt.CompressFramework
+        cf.Compress.divide.divide_type = "adaptive_-1_-1_0_0_20"
+        cf.Compress.divide.param_alloc = "by_dv"
+        cf.Compress.max_steps, cf.Compress.checkpoints, cf.Compress.loss_log_freq = steps, "none", 10 ** 9
+        cf.Decompress.mip = False
+        cf["_seed"] = 42
+        Log = MyLogger(outputs_dir=work, project_name="c5", time=False)
+        torch.manual_seed(42)
+        fw = NFGR(cf, Log=Log)
+        res = fw.compress_divide(path, opt)
+        cdir = os.path.join(Log.logdir, "steps%d" % steps, "compressed")
+        names = sorted(os.listdir(os.path.join(cdir, "module")))
+        cover = np.zeros(vol.shape[:3], np.int8)
+        sizes = set()
+        for nm in names:
+            r = misc.parse_chunk_name(nm)
+            sizes.add(tuple(r[a][1] - r[a][0] + 1 for a in ("d", "h", "w")))
+            cover[r["d"][0]:r["d"][1] + 1, r["h"][0]:r["h"][1] + 1, r["w"][0]:r["w"][1] + 1] += 1
+        assert 8 <= len(names) <= 20 and len(sizes) >= 2 and cover.max() == 1
+        assert (vol[..., 0][cover == 0] == 0).all()                      # what belongs to no block is a pruned all-zero region
+        feats = [int(config.load(os.path.join(cdir, "sideinfos", nm, "sideinfos.yaml"))["phi_features"]) for nm in names]
+        total = sum(SIREN.calc_param_count(3, 1, f, 7) for f in feats) * 4
+        budget = os.path.getsize(path) / 128.0
+        assert abs(total - budget) / budget < 0.10 and len(set(feats)) >= 2      # by_dv: the blocks share the ratio-128 budget unevenly
+        merged = np.load(os.path.join(Log.logdir, "steps%d" % steps, "decompressed", "vessel_decompressed.npy"))
+        dd = merged.astype(np.float64) - vol.astype(np.float64)
+        assert abs(-10 * np.log10((dd * dd).mean() / 65535.0 ** 2) - res[steps]["psnr"]) < 1e-6
+        assert (merged[..., 0][cover == 0] == 0).all() and res[steps]["psnr"] > 25
+        first, f0, l1, worst = _pin_first_block(fw, cf, Log.logdir, steps, vol, work, 7)
+        print("C5 64x512x512 vessel: %d blocks of %d sizes, features %s, %d steps, PSNR %.2f dB SSIM %.4f; block %s (F = %d) byte-equal to its SingleTask fit, "
+              "first-step worst gradient tensor vs oracle %.2e" % (len(names), len(sizes), sorted(set(feats)), steps, res[steps]["psnr"], res[steps]["ssim"], first, f0, worst))
+    finally:
+        shutil.rmtree(work, ignore_errors=True)

@@ -496,3 +496,32 @@ def test_init_net_path_warm_start_and_half_option(tmp_path):
     side = config.load(os.path.join(Log3.logdir, "steps150", "compressed", "sideinfos.yaml"))
     assert side["phi_features"] == SIREN.calc_features(given / 2.0, 3, 1, 4) > 24 and side["phi_precision"] == "bf16"
     assert r3[150]["psnr"] > 25
+
+
+def test_bench_dividetask_path_on_the_rccl_backend_world_size_one():
+    """the code a multi-GPU SCALE run executes, on the one GPU of the test box: bench.py --divide initialises the **nccl**
+    (RCCL) process group with one rank and drives NFGR.compress_divide through divide_bench: broadcast_object_list of the
+    block list and the run directory, device-tensor all-reduces ([SSE, SSIM-sum, slices, voxels], the timed-window MAX),
+    barriers with device_id set.  Also: --gpus N must equal the launcher's world size, and --gpus N without a launcher
+    starts the ranks itself (refused here: one device)."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--divide", "--block", "128", "--steps", "4", "--warmup", "2", "--preroll", "4",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 1 and out["metric"] == "encode_voxels_per_sec" and out["value"] > 1e6 and out["scaling"] == "weak"
+    assert out["config"]["volume"] == [128, 128, 128] and "DivideTask" in out["config"]["workload"]
+    assert 10.0 < out["psnr_at_bitrate"]["psnr_db"] < 100.0 and 0.0 < out["psnr_at_bitrate"]["ssim"] <= 1.0
+    assert 0.0 < out["roofline"]["frac"] < 1.0
+    # a launcher whose world size differs from --gpus is an error, not a silent one-rank run
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True, timeout=300,
+                        env={**env, "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r2.returncode == 2 and "WORLD_SIZE" in r2.stderr
+    if torch.cuda.device_count() < 2:
+        r3 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True, timeout=300, env=env)
+        assert r3.returncode == 2 and "device" in r3.stderr

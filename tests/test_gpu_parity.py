@@ -529,6 +529,41 @@ def test_steplr_schedule_matches_torch():
     assert b.t == 10 and log.shape == (10,) and torch.equal(a.m.params, b.m.params)
 
 
+def test_cyclic_lr_and_index_stream_run_inside_the_cabi_loop():
+    """brief_fit_job's lr_table / beta1_table (CyclicLR cycles Adam's beta1) and its device-resident index stream (windowed
+    RandomCubeSampler, main.py:38-125): run(k) in one brief_siren_fit call == k x step(), bit for bit; a run that is cut into
+    several calls by the index-stream memory budget too."""
+    from brief_pytorch_amd.fit import Fitter
+    from brief_pytorch_amd.framework import _CubeIndexStream
+    sched = {"name": "CyclicLR", "base_lr": 1e-4, "max_lr": 2e-3, "step_size_up": 5, "step_size_down": 3, "mode": "triangular2"}
+    a = _mk_fitter(4, 48, (8, 16, 16), "randompoint", 700, 21, sched, "Adam")
+    b = _mk_fitter(4, 48, (8, 16, 16), "randompoint", 700, 21, sched, "Adam")
+    ref = [float(a.step()) for _ in range(19)]
+    got = torch.cat([b.run(8, log=True), b.run(11, log=True)]).cpu().numpy()
+    assert np.array_equal(np.asarray(ref, np.float32), got)
+    assert torch.equal(a.m.params, b.m.params) and torch.equal(a.s1, b.s1) and torch.equal(a.s2, b.s2) and torch.equal(a.m.packed, b.m.packed)
+    # windowed cube sampler: the window draws come from a generator seeded alike on both sides
+    dims, cl = (12, 20, 16), (5, 8, 6)
+    fits = []
+    for k in range(3):
+        torch.manual_seed(5)
+        m = SIREN(features=40, layers=4, w0=20.0).to(DEV)
+        tv = (torch.rand(int(np.prod(dims)), 1, generator=torch.Generator().manual_seed(6)) * 100).to(DEV)
+        st = _CubeIndexStream(dims, cl, 3, DEV, generator=torch.Generator().manual_seed(99))
+        fits.append(Fitter(m, tv, dims, sampler="randompoint", sample_size=st.n, index_stream=st, scheduler={"name": "StepLR", "step_size": 3, "gamma": 0.7}))
+    ref = [float(fits[0].step()) for _ in range(10)]
+    got = fits[1].run(10, log=True).cpu().numpy()
+    assert np.array_equal(np.asarray(ref, np.float32), got) and torch.equal(fits[0].m.params, fits[1].m.params)
+    fits[2].INDEX_STREAM_BYTES = 8 * fits[2].n * 4              # four steps per call: 10 steps = 3 calls
+    got3 = fits[2].run(10, log=True).cpu().numpy()
+    assert fits[2].max_steps_per_call() == 4 and np.array_equal(got, got3) and torch.equal(fits[1].m.params, fits[2].m.params)
+    # a job whose index pointer has no stride is refused
+    j, _ = fits[1].job(2)
+    j.idx_stride = 0
+    import ctypes as C
+    assert _lib.lib().brief_siren_fit(C.byref(j), 2, _lib.stream_ptr()) != 0 and b"idx_stride" in _lib.lib().brief_last_error()
+
+
 def test_multi_fit_equals_individual_fits():
     """brief_multi_fit: blocks co-trained on internal streams give exactly the results of fitting each alone
     (10 jobs > 8 pool streams: two jobs share a stream)."""
@@ -551,12 +586,23 @@ def test_multi_fit_equals_individual_fits():
         assert logs[i].shape == (18,) and torch.isfinite(logs[i]).all()
 
 
-def test_fit_job_rejects_replayed_indices():
+def test_fit_job_replays_an_index_stream_and_rejects_a_malformed_one():
+    """a replayed per-step index stream (any callable t -> indices) runs inside brief_siren_fit as a device-resident
+    [steps, n] tensor: same bits as step(); a stream of the wrong length or dtype is refused before the launch"""
     from brief_pytorch_amd._lib import BriefError
-    f = _mk_fitter(3, 16, (8, 8, 8), "randompoint", 100, 1)
-    f.index_stream = lambda t: torch.zeros(100, dtype=torch.int64, device=DEV)
+    gens = [torch.Generator().manual_seed(3) for _ in range(2)]
+    fa, fb = (_mk_fitter(3, 16, (8, 8, 8), "randompoint", 100, 1) for _ in range(2))
+    fa.index_stream = lambda t: torch.randint(0, 512, (100,), generator=gens[0]).to(DEV)
+    fb.index_stream = lambda t: torch.randint(0, 512, (100,), generator=gens[1]).to(DEV)
+    ref = [float(fa.step()) for _ in range(6)]
+    got = fb.run(6, log=True).cpu().numpy()
+    assert np.array_equal(np.asarray(ref, np.float32), got) and torch.equal(fa.m.params, fb.m.params)
+    fb.index_stream = lambda t: torch.zeros(99, dtype=torch.int64, device=DEV)
     with pytest.raises(BriefError):
-        f.run(2)
+        fb.run(2)
+    fb.index_stream = lambda t: torch.zeros(100, dtype=torch.int32, device=DEV)
+    with pytest.raises(BriefError):
+        fb.run(2)
 
 
 def test_in_kernel_sampling_equals_index_kernel():
