@@ -1517,7 +1517,7 @@ __global__ __launch_bounds__(1024) void k_reduce(const ReduceArgs a, int nb_hidd
             else so = (int64_t)FP * FP + (r - (int64_t)F * F);
             const int64_t slab_sz = (int64_t)FP * FP + FP;
             const float *base = a.slabs + (int64_t)(l - 1) * a.nsplit * slab_sz + so;
-#pragma unroll 8
+#pragma unroll 16
             for (int sp = sg; sp < a.nsplit; sp += SG) s += base[(int64_t)sp * slab_sz];
         }
         if (SG > 1) {
@@ -1575,7 +1575,8 @@ __global__ __launch_bounds__(1024) void k_reduce(const ReduceArgs a, int nb_hidd
     }
     // record index of (wg, ws) for this wm: (wg*4 + ws*WM + wmo); enumerate q = wg*WS + ws
     float s = 0.f;
-    for (int q = lane; q < nrec; q += 64) {
+#pragma unroll 8
+    for (int q = lane; q < nrec; q += 64) {      // (unrolled: the loads of a lane are independent, only the adds are ordered)
         const int wg = q / WS, w = q % WS;
         s += a.rec[((int64_t)wg * 4 + w * WM + wmo) * BRIEF_REC_FLOATS + slot];
     }
@@ -1885,6 +1886,7 @@ static const int kRecWgsPerCu = 8;      // per-workgroup record slots per CU in 
 static const int g_wg_per_cu = env_int("BRIEF_WG_PER_CU", BRIEF_TRAIN_WPE, 1, 4);
 static const int g_stagger = env_int("BRIEF_STAGGER", 1, 0, 64);
 static const int g_diag = env_int("BRIEF_DIAG", 0, 0, 255);
+static const int g_reduce_sg_small = env_int("BRIEF_REDUCE_SG", 0, 0, 64);      // diagnostics: k_reduce threads per hidden parameter behind k_small (power of two; 0 = by slab count)
 static int fused_grid(const brief_siren_desc &d, int64_t n, bool train)
 {
     (void)train;
@@ -2318,10 +2320,14 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
     ReduceArgs ra;
     memset(&ra, 0, sizeof(ra));
     ra.d = *d; ra.rec = fa.rec; ra.nrec_wg = grid1; ra.slabs = ws + wl.slabs; ra.nsplit = nsplit;
-    // threads per hidden parameter: k_small leaves one slab per workgroup (<= 2 x CUs of them): 8 threads x 64 slabs;
-    // k_wgrad <= 85 slabs: 4 threads x ~21.  The group sums are added in group order (bit-reproducible).  (32 threads per
-    // parameter in 1024-thread blocks were measured slower for the narrow nets: 0.090 against 0.083 ms per 4x22 step.)
-    ra.sgroups = small ? 8 : 4;
+    // threads per hidden parameter: k_small leaves one slab per workgroup (<= 2 x CUs of them): 16 slabs per thread, i.e.
+    // 32 threads per parameter for 512 slabs — every thread's loads are then ONE round trip to HBM instead of eight (measured,
+    // tools/ab_reduce.sh: 4x22 on 64^3 0.084 -> 0.072 ms per step, 2x64 0.111 -> 0.103; 64 threads per parameter: 0.076).
+    // k_wgrad <= 85 slabs: 4 threads x ~21.  The group sums are added in group order (bit-reproducible).
+    int sg_small = 8;
+    while (sg_small < 32 && sg_small * 16 < nsplit) sg_small *= 2;
+    if (g_reduce_sg_small > 0) sg_small = g_reduce_sg_small;
+    ra.sgroups = small ? sg_small : 4;
     const int rthreads = 256;
     ra.grads = grads; ra.loss_out = loss_out; ra.inv_count = inv_count;
     if (upd) { ra.update = 1; ra.opt = upd->opt; ra.params = upd->params; ra.s1 = upd->s1; ra.s2 = upd->s2; ra.pk = upd->pk; }

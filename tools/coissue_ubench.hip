@@ -154,6 +154,52 @@ __global__ __launch_bounds__(512) void k_cross(float *out, long long *cycles, in
     EPILOGUE(t1 - t0, k_cross)
 }
 
+// (3b) as (3) with bf16 MFMAs in waves 0-3.  mode bit 7: the VALU waves run a { 1 v_sin ; 1 v_fma } mix (a sine epilogue's shape)
+__global__ __launch_bounds__(512) void k_cross16(float *out, long long *cycles, int iters, int mode)
+{
+    PROLOGUE
+    const int wave = threadIdx.x >> 6;
+    long long t0 = 0, t1 = 0;
+    if (wave < 4) {
+        if (mode & 1) {
+            const int p = (mode >> 4) & 3;
+            if (p == 1) __builtin_amdgcn_s_setprio(1); else if (p == 2) __builtin_amdgcn_s_setprio(2); else if (p == 3) __builtin_amdgcn_s_setprio(3);
+            t0 = __builtin_amdgcn_s_memtime();
+            for (int it = 0; it < iters; ++it) asm volatile(B8(NOFILL) ASM_OPERANDS);
+            t1 = __builtin_amdgcn_s_memtime();
+        }
+    } else {
+        if (mode & 2) {
+            const int p = (mode >> 2) & 3;
+            if (p == 1) __builtin_amdgcn_s_setprio(1); else if (p == 2) __builtin_amdgcn_s_setprio(2); else if (p == 3) __builtin_amdgcn_s_setprio(3);
+            t0 = __builtin_amdgcn_s_memtime();
+            if (mode & 128) for (int it = 0; it < iters; ++it) asm volatile(R8(VS(0) VF(1) VS(2) VF(3)) ASM_OPERANDS);      // 16 v_sin + 16 v_fma
+            else if (mode & 64) for (int it = 0; it < iters; ++it) asm volatile(R4(S8) ASM_OPERANDS);
+            else for (int it = 0; it < iters; ++it) asm volatile(R8(V8) ASM_OPERANDS);
+            t1 = __builtin_amdgcn_s_memtime();
+        }
+    }
+    EPILOGUE(t1 - t0, k_cross16)
+}
+
+// (4b) two waves per SIMD, both { 64 bf16 MFMA ; 64 x (v_sin, v_fma) }: in phase / out of phase
+__global__ __launch_bounds__(512) void k_phase16(float *out, long long *cycles, int iters, int mode)
+{
+    PROLOGUE
+    const int wave = threadIdx.x >> 6;
+    const bool second = wave >= 4;
+    if (second && !(mode & 2)) return;
+    if (!second && !(mode & 1)) return;
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    if (second && (mode & 4)) asm volatile(R8(R8(VS(0) VF(1))) ASM_OPERANDS);
+    for (int it = 0; it < iters; ++it) {
+        asm volatile(R8(B8(NOFILL)) ASM_OPERANDS);
+        asm volatile(R8(R8(VS(0) VF(1))) ASM_OPERANDS);
+    }
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    EPILOGUE(t1 - t0, k_phase16)
+}
+
 // (4) two waves per SIMD, both { 64 MFMA ; 512 v_fma } ; waves 4-7 start with the VALU part (out of phase)
 __global__ __launch_bounds__(512) void k_phase(float *out, long long *cycles, int iters, int mode)
 {
@@ -218,5 +264,14 @@ int main()
     printf("(4) two waves per SIMD, both { 64 MFMA ; 512 v_fma }\n");
     struct { const char *n; int mode; } ph[] = {{"first half alone", 1}, {"both in phase", 3}, {"both out of phase", 7}};
     for (auto &c : ph) run(c.n, [&] { hipLaunchKernelGGL(k_phase, dim3(256), dim3(512), 0, 0, d_out, d_cyc, it / 8, c.mode); }, 8, it / 8 * 64.0, "MFMA");
+    printf("(3b) two waves per SIMD: waves 0-3 bf16 MFMA (8 per iteration), waves 4-7 VALU (64 v_fma | 32 v_sin | 16 v_sin + 16 v_fma per iteration)\n");
+    struct { const char *n; int mode; } cr16[] = {
+        {"bf16 mfma alone", 1}, {"v_fma alone", 2}, {"both", 3}, {"both, valu prio 3", 3 | (3 << 2)}, {"both, mfma prio 3", 3 | (3 << 4)},
+        {"v_sin alone", 2 | 64}, {"both sin", 3 | 64}, {"both sin, valu prio 3", 3 | 64 | (3 << 2)},
+        {"sin+fma mix alone", 2 | 128}, {"both mix", 3 | 128}, {"both mix, valu prio 3", 3 | 128 | (3 << 2)}, {"both mix, mfma prio 3", 3 | 128 | (3 << 4)}};
+    for (auto &c : cr16) run(c.n, [&] { hipLaunchKernelGGL(k_cross16, dim3(256), dim3(512), 0, 0, d_out, d_cyc, it, c.mode); }, 8, it * 8.0, "8");
+    printf("(4b) two waves per SIMD, both { 64 bf16 MFMA ; 64 x (v_sin, v_fma) }\n");
+    struct { const char *n; int mode; } ph16[] = {{"first half alone", 1}, {"both in phase", 3}, {"both out of phase", 7}};
+    for (auto &c : ph16) run(c.n, [&] { hipLaunchKernelGGL(k_phase16, dim3(256), dim3(512), 0, 0, d_out, d_cyc, it / 8, c.mode); }, 8, it / 8 * 64.0, "MFMA");
     return 0;
 }
