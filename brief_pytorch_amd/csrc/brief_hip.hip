@@ -92,7 +92,7 @@ struct FusedArgs {
     float *rec;          // [gridDim.x*4][BRIEF_REC_FLOATS]
     int64_t n_begin, n_end;   // bf16 path: the sample range of this launch (body / tail launches)
     int rec_base;             // bf16 path: first record slot of this launch
-    void *S16[5];        // bf16 path: stashes H | C | D ([(L-1)][FP][npad] bf16 each), X [4][npad], G [4][npad]
+    void *S16[5];        // bf16 path: stashes THETA (fp16 phases) | unused | D (bf16 deltas) ([(L-1)][FP][npad] each), X [4][npad], G [4][npad]
     float *slabs;        // k_small only: [(L-2)][gridDim.x][FP*FP + FP] per-workgroup hidden-layer gradient partials
     float *yhat_out;     // [n][cout] or NULL
     void *out;           // forward output
@@ -1886,6 +1886,7 @@ static const int kRecWgsPerCu = 8;      // per-workgroup record slots per CU in 
 static const int g_wg_per_cu = env_int("BRIEF_WG_PER_CU", BRIEF_TRAIN_WPE, 1, 4);
 static const int g_stagger = env_int("BRIEF_STAGGER", 1, 0, 64);
 static const int g_diag = env_int("BRIEF_DIAG", 0, 0, 255);
+static const int g_reduce_sg_big = env_int("BRIEF_REDUCE_SG_BIG", 4, 1, 64);
 static const int g_reduce_sg_small = env_int("BRIEF_REDUCE_SG", 0, 0, 64);      // diagnostics: k_reduce threads per hidden parameter behind k_small (power of two; 0 = by slab count)
 static int fused_grid(const brief_siren_desc &d, int64_t n, bool train)
 {
@@ -1986,13 +1987,13 @@ static int wgrad16_skinny_splits(const brief_siren_desc &d, int64_t n)
     if (s > nblk) s = nblk;
     return (int)(s < 1 ? 1 : s);
 }
-struct Ws16 { int64_t h, c, dd, x, g, rec, slabs, total; };      // offsets in floats
+struct Ws16 { int64_t h, dd, x, g, rec, slabs, total; };      // offsets in floats (h: the fp16 phase planes, dd: the bf16 delta planes)
 static Ws16 ws16_layout(const brief_siren_desc &d, int64_t n)
 {
     const int64_t FP = 32 * brief_nt(d), np = npad16(n), planes = d.layers - 1, hidden = d.layers - 2 > 0 ? d.layers - 2 : 0;
     const int64_t stash = planes * FP * np / 2;                       // bf16 elements -> float slots (np is a multiple of 128)
     Ws16 w;
-    w.h = 0; w.c = w.h + stash; w.dd = w.c + stash;
+    w.h = 0; w.dd = w.h + stash;
     w.x = w.dd + stash; w.g = w.x + 4 * np / 2;
     w.rec = w.g + 4 * np / 2;
     w.slabs = w.rec + (int64_t)2 * kCUs * 8 /* body + tail launches */ + (int64_t)kCUs * 8 * 10 /* diagnostic stamps */;
@@ -2219,7 +2220,7 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
         fa.loss_kind = loss_kind; fa.thr = thr; fa.beta = beta; fa.inv_count = inv16;
         fa.npad = np; fa.rec = ws + w16.rec; fa.yhat_out = yhat_out; fa.diag = g_diag;
         fa.stagger_cus = kCUs; fa.stagger = g_stagger;
-        fa.S16[0] = ws + w16.h; fa.S16[1] = ws + w16.c; fa.S16[2] = ws + w16.dd; fa.S16[3] = ws + w16.x; fa.S16[4] = ws + w16.g;
+        fa.S16[0] = ws + w16.h; fa.S16[1] = nullptr; fa.S16[2] = ws + w16.dd; fa.S16[3] = ws + w16.x; fa.S16[4] = ws + w16.g;
         const bool prof16 = g_prof_on && g_prof_n < kProfSlots;
         if (prof16) HIP_TRY(hipEventRecord(g_prof_ev[2 * g_prof_n], st));
         if (int rc = launch_k16_split<true>(fa, st)) return rc;
@@ -2327,7 +2328,7 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
     int sg_small = 8;
     while (sg_small < 32 && sg_small * 16 < nsplit) sg_small *= 2;
     if (g_reduce_sg_small > 0) sg_small = g_reduce_sg_small;
-    ra.sgroups = small ? sg_small : 4;
+    ra.sgroups = small ? sg_small : g_reduce_sg_big;
     const int rthreads = 256;
     ra.grads = grads; ra.loss_out = loss_out; ra.inv_count = inv_count;
     if (upd) { ra.update = 1; ra.opt = upd->opt; ra.params = upd->params; ra.s1 = upd->s1; ra.s2 = upd->s2; ra.pk = upd->pk; }

@@ -15,7 +15,7 @@ torch.cuda.synchronize()
 FP = 256 if F <= 256 else 512
 npad = (100000 + 127) // 128 * 128
 stash = (L - 1) * FP * npad // 2
-rec_off = 3 * stash + 2 * (4 * npad // 2)
+rec_off = 2 * stash + 2 * (4 * npad // 2)      # phase + delta planes (round 3: no cosine plane)
 st = m._ws[rec_off + 2 * 256 * 8: rec_off + 2 * 256 * 8 + 256 * 8 * 10].view(256 * 8, 10).cpu().numpy()
 names = ['inputs+layer0', 'fwd chain', 'barrier after chain', 'fwd epilogue (sin/cos, stash, image)', 'barrier after image', 'head+loss+Wh^T g',
          'bwd epilogue (c load, mult, D stash)', 'bwd barriers + image', 'bwd chain', 'tile-end barrier']
