@@ -496,7 +496,7 @@ def main():
         # read from the committed counter passes of this same command (tools/profile_round.sh: separate --pmc FETCH_SIZE /
         # WRITE_SIZE passes, 2*FETCH_SIZE + WRITE_SIZE per launch, the guide's gfx950 correction) and labelled as such
         traffic, traffic_src = None, None
-        for tag in ("r02", "r01"):
+        for tag in ("r03", "r02", "r01"):
             try:
                 with open(os.path.join(ROOT, "profiles", tag + "_traffic.json")) as f:
                     traffic = float(json.load(f)["k_fused"]["hbm_bytes"])

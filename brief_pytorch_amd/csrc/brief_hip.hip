@@ -1517,8 +1517,14 @@ __global__ __launch_bounds__(1024) void k_reduce(const ReduceArgs a, int nb_hidd
             else so = (int64_t)FP * FP + (r - (int64_t)F * F);
             const int64_t slab_sz = (int64_t)FP * FP + FP;
             const float *base = a.slabs + (int64_t)(l - 1) * a.nsplit * slab_sz + so;
+            if (SG >= 16) {
+                // k_small's one slab per workgroup: <= 16 terms per thread, all loads in flight at once
 #pragma unroll 16
-            for (int sp = sg; sp < a.nsplit; sp += SG) s += base[(int64_t)sp * slab_sz];
+                for (int sp = sg; sp < a.nsplit; sp += SG) s += base[(int64_t)sp * slab_sz];
+            } else {
+#pragma unroll 8
+                for (int sp = sg; sp < a.nsplit; sp += SG) s += base[(int64_t)sp * slab_sz];
+            }
         }
         if (SG > 1) {
             fold[threadIdx.x] = s;
@@ -1575,7 +1581,7 @@ __global__ __launch_bounds__(1024) void k_reduce(const ReduceArgs a, int nb_hidd
     }
     // record index of (wg, ws) for this wm: (wg*4 + ws*WM + wmo); enumerate q = wg*WS + ws
     float s = 0.f;
-#pragma unroll 8
+#pragma unroll 4
     for (int q = lane; q < nrec; q += 64) {      // (unrolled: the loads of a lane are independent, only the adds are ordered)
         const int wg = q / WS, w = q % WS;
         s += a.rec[((int64_t)wg * 4 + w * WM + wmo) * BRIEF_REC_FLOATS + slot];

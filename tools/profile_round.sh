@@ -7,9 +7,9 @@ tag=${1:-r01}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o p -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-psnr > $out/bench_trace_run.json 2> $out/trace.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -o p -- python3 bench.py --steps 10 --warmup 2 --preroll 20 --preroll-seconds 0 --no-cpu-baseline --no-psnr > /dev/null 2> $out/fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -o p -- python3 bench.py --steps 10 --warmup 2 --preroll 20 --preroll-seconds 0 --no-cpu-baseline --no-psnr > /dev/null 2> $out/write.err
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $out/sq -o p -- python3 bench.py --steps 10 --warmup 2 --preroll 20 --preroll-seconds 0 --no-cpu-baseline --no-psnr > /dev/null 2> $out/sq.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o p -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-psnr --no-extras > $out/bench_trace_run.json 2> $out/trace.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -o p -- python3 bench.py --steps 10 --warmup 2 --preroll 20 --preroll-seconds 0 --no-cpu-baseline --no-psnr --no-extras > /dev/null 2> $out/fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -o p -- python3 bench.py --steps 10 --warmup 2 --preroll 20 --preroll-seconds 0 --no-cpu-baseline --no-psnr --no-extras > /dev/null 2> $out/write.err
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $out/sq -o p -- python3 bench.py --steps 10 --warmup 2 --preroll 20 --preroll-seconds 0 --no-cpu-baseline --no-psnr --no-extras > /dev/null 2> $out/sq.err
 python3 bench.py > $out/bench_default.json 2> $out/bench_default.err
 echo done
