@@ -8,8 +8,8 @@ cfg=${2:-c3}
 out=gpurun_out/prof16_${tag}_${cfg}
 mkdir -p $out
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o p -- python3 bench.py --config $cfg --precision bf16 --steps 40 --warmup 5 --no-cpu-baseline --no-psnr > $out/bench_trace_run.json 2> $out/trace.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -o p -- python3 bench.py --config $cfg --precision bf16 --steps 6 --warmup 2 --preroll 2 --preroll-seconds 0 --no-cpu-baseline --no-psnr > /dev/null 2> $out/fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -o p -- python3 bench.py --config $cfg --precision bf16 --steps 6 --warmup 2 --preroll 2 --preroll-seconds 0 --no-cpu-baseline --no-psnr > /dev/null 2> $out/write.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o p -- python3 bench.py --config $cfg --precision bf16 --steps 40 --warmup 5 --no-cpu-baseline --no-psnr --no-extras > $out/bench_trace_run.json 2> $out/trace.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -o p -- python3 bench.py --config $cfg --precision bf16 --steps 6 --warmup 2 --preroll 2 --preroll-seconds 0 --no-cpu-baseline --no-psnr --no-extras > /dev/null 2> $out/fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -o p -- python3 bench.py --config $cfg --precision bf16 --steps 6 --warmup 2 --preroll 2 --preroll-seconds 0 --no-cpu-baseline --no-psnr --no-extras > /dev/null 2> $out/write.err
 python3 tools/pmc_summary.py $out/fetch/p_counter_collection.csv $out/write/p_counter_collection.csv > $out/pmc.txt 2>&1
 echo done
