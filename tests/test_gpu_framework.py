@@ -525,3 +525,28 @@ def test_bench_dividetask_path_on_the_rccl_backend_world_size_one():
     if torch.cuda.device_count() < 2:
         r3 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True, timeout=300, env=env)
         assert r3.returncode == 2 and "device" in r3.stderr
+
+
+def test_adaptive_octree_device_statistics_choose_the_pinned_partition():
+    """volumes of 2^24 voxels or more take their octree variances and FFT features from the GPU (torch float64 reductions,
+    rocFFT) instead of numpy, whose arithmetic tests/golden/adaptive.npz pins: on a 128^3 volume with an all-zero octant
+    both routes must prune the same nodes, agree on every node's feature to 1e-9 relative, and choose the SAME partition
+    (the knapsack only sees differences that flip a comparison)."""
+    from brief_pytorch_amd import adaptive_blocking as ab
+    from brief_pytorch_amd.synthetic import make_volume
+    vol = make_volume((128, 128, 128), seed=61)
+    vol[64:, :64, 64:] = 0
+    data = vol
+    Nb, minl, maxl = ab.adaptive_levels(20, 0, 3)
+    trees = {}
+    for dev in (None, "cuda"):
+        root = ab.build_tree(data.shape, maxl, 3)
+        ab.prune_and_score(root, data, 0, 0, dim=3, device=dev)
+        active, best = ab.solve_tree(root, Nb, minl, 3)
+        trees[dev] = (root, sorted((p.z, p.y, p.x, p.d, p.h, p.w) for p in active), best)
+    nodes_a, nodes_b = list(ab.iter_nodes(trees[None][0])), list(ab.iter_nodes(trees["cuda"][0]))
+    assert len(nodes_a) == len(nodes_b) and [n.pruned for n in nodes_a] == [n.pruned for n in nodes_b]
+    assert any(n.pruned for n in nodes_a)
+    fa = np.array([n.feature for n in nodes_a if not n.pruned]); fb = np.array([n.feature for n in nodes_b if not n.pruned])
+    assert np.max(np.abs(fa - fb) / np.abs(fa)) < 1e-9
+    assert trees[None][1] == trees["cuda"][1] and abs(trees[None][2] - trees["cuda"][2]) <= 1e-9 * abs(trees[None][2])
