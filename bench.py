@@ -197,7 +197,8 @@ def launch_ranks(args):
     that touched the GPU, and this one has not touched it yet either) and hand its exit code back"""
     import socket
     import subprocess
-    if args.gpus > torch.cuda.device_count():           # (counting devices does not initialise the GPU)
+    shared = os.environ.get("BRIEF_DIST_BACKEND", "nccl") == "gloo" and os.environ.get("BRIEF_SHARE_GPU") == "1"      # rehearsal: ranks share devices
+    if args.gpus > torch.cuda.device_count() and not shared:           # (counting devices does not initialise the GPU)
         sys.stderr.write("bench.py: --gpus %d but only %d device(s) are visible\n" % (args.gpus, torch.cuda.device_count()))
         sys.exit(2)
     sock = socket.socket()

@@ -525,6 +525,13 @@ def test_bench_dividetask_path_on_the_rccl_backend_world_size_one():
     if torch.cuda.device_count() < 2:
         r3 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True, timeout=300, env=env)
         assert r3.returncode == 2 and "device" in r3.stderr
+    # the self-launch itself, rehearsed with two gloo ranks sharing this GPU: bench.py starts `torch.distributed.run` as a child,
+    # the two ranks run the DivideTask path on a 2 x 128^3 volume and rank 0 prints the one line
+    r4 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--block", "128", "--steps", "4", "--warmup", "2", "--preroll", "4",
+                         "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env={**env, "BRIEF_DIST_BACKEND": "gloo", "BRIEF_SHARE_GPU": "1"})
+    assert r4.returncode == 0, r4.stderr[-3000:]
+    out2 = json.loads([l for l in r4.stdout.splitlines() if l.startswith("{")][-1])
+    assert out2["n_gpus"] == 2 and out2["config"]["volume"] == [256, 128, 128] and out2["value"] > 1e6 and 10.0 < out2["psnr_at_bitrate"]["psnr_db"] < 100.0
 
 
 def test_adaptive_octree_device_statistics_choose_the_pinned_partition():
