@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define BRIEF_VERSION 100 /* 0.1.0 */
+#define BRIEF_VERSION 110 /* 0.1.1: brief_fit_job grew (lr_table, beta1_table, idx_stride); the derived weight copies carry the sine frequencies */
 
 typedef enum {
     BRIEF_OK = 0,
