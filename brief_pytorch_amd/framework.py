@@ -20,10 +20,10 @@ import torch
 
 from . import _lib, config
 from .fit import Fitter
-from .io import get_folder_size, get_type_max, invnormalize_data, minmaxany_range, normalize_data, save_yaml, load_yaml
+from .io import get_folder_size, get_type_max, invnormalize_data, minmaxany_range, normalize_data, normalize_data_device, save_yaml, load_yaml
 from .metrics import cal_ssim, eval_performance, gpu_eval_u16, gpu_ssim_u16, psnr_from_sse
 from .misc import (alloc_param, cal_divide_num, divide_data, merge_divided_data, mip_ops, save_mips, parse_checkpoints,
-                   parse_chunk_name, parse_weight, preprocess, preprocess_is_identity)
+                   parse_chunk_name, parse_weight, preprocess, preprocess_is_identity, weight_is_unit)
 from .modelsave import CopyDir, load_model, save_model
 from .networks import (ALL_CALC_PHI_FEATURES, ALL_CALC_PHI_PARAM_COUNT, get_nnmodule_param_count, init_phi)
 from .tool import create_stack, read_img, save_img, write_slab
@@ -187,20 +187,24 @@ class NFGR:
         pre = preprocess(data, C_.preprocess.denoise.level, C_.preprocess.denoise.close, C_.preprocess.clip)
         name, ext = ops(opb(data_path))
         save_img(opj(logdir, name + "_preprocessed" + ext), pre)
-        weight = parse_weight(pre, C_.loss.weight).astype(np.float32, copy=False)     # ('exp_x_v' on integer data is float64)
-        norm, sideinfos = normalize_data(pre, **opt.Normalize)
+        # loss weights (utils/misc.py:272-307): a map is only built when the spec can produce something else than ones
+        weight = None if weight_is_unit(C_.loss.weight) else parse_weight(pre, C_.loss.weight).astype(np.float32, copy=False)     # ('exp_x_v' on integer data is float64)
+        # normalise on the device (bit-identical to utils/io.py:65-80, io.normalize_data_device): the targets live there anyway
+        tgt_dev, sideinfos = normalize_data_device(pre, opt.Normalize.name, self.device)
         ideal = self.parse_param_size(data_path)
         feats, theory_size = self.prepare_module(ideal)
         phi = self.module["phi"]
         if C_.param.init_net_path != "none":
             load_model(phi, C_.param.init_net_path, "cpu")
-        sideinfos = {**sideinfos, "data_shape": list(norm.shape), "phi_features": feats, "phi_name": opt.Module.phi.name}
+        sideinfos = {**sideinfos, "data_shape": list(pre.shape), "phi_features": feats, "phi_name": opt.Module.phi.name}
         if self.precision != "fp32":
             sideinfos["phi_precision"] = self.precision      # extra key only off the reference's fp32 path
-        dims = list(norm.shape[:-1])
-        cout = norm.shape[-1]
-        tgt = norm.reshape(-1, cout).to(self.device)
-        wts = None if bool(np.all(weight == 1.0)) else torch.from_numpy(np.ascontiguousarray(weight.reshape(-1, cout))).to(self.device)
+        dims = list(pre.shape[:-1])
+        cout = pre.shape[-1]
+        tgt = tgt_dev.reshape(-1, cout)
+        wts = None
+        if weight is not None and not bool(np.all(weight == 1.0)):
+            wts = torch.from_numpy(np.ascontiguousarray(weight.reshape(-1, cout))).to(self.device)
         assert C_.loss.weight_thres <= get_type_max(pre), "The weight threshold should be less than the data maximum!"
         thr_t, _ = normalize_data(np.array(C_.loss.weight_thres), **opt.Normalize, max=sideinfos["max"], min=sideinfos["min"])
         thr = float(thr_t)

@@ -69,6 +69,34 @@ def normalize_data(data, name, min=None, max=None):
     raise NotImplementedError(name)
 
 
+def normalize_data_device(data, name, device, min=None, max=None):
+    """normalize_data for the 'minmaxany_a_b' rule with the arithmetic on `device`: the same float32 operations in the same
+    order as the host version (utils/io.py:65-80: cast, subtract, divide, scale, shift — each its own rounding, IEEE on both
+    sides), so the result is bit-identical (tests/test_gpu_framework.py) while a 512^3 volume stops costing eight host passes
+    over half a gigabyte.  Returns (device float32 tensor, sideinfos); other rules and dtypes go through normalize_data."""
+    if "minmaxany" not in name or data.dtype not in (np.uint8, np.uint16, np.int16, np.float32):
+        t, side = normalize_data(data, name, min=min, max=max)
+        return t.to(device), side
+    scale_min, scale_max = (float(v) for v in name.split("_")[1:])
+    dtype = data.dtype.name
+    a = np.ascontiguousarray(data)
+    if a.dtype == np.uint16:      # torch has no uint16 arithmetic: move the bits, widen on the device
+        x = (torch.from_numpy(a.view(np.int16)).to(device).to(torch.int32) & 0xFFFF).to(torch.float32)
+    else:
+        x = torch.from_numpy(a).to(device).to(torch.float32)
+    if min is None:
+        min = float(x.min().item())
+    if max is None:
+        max = float(x.max().item())
+    # (operands as 0-d DEVICE tensors: torch turns `tensor / python_scalar` into a multiplication by the reciprocal on the GPU)
+    c = lambda v: torch.tensor(np.float32(v), dtype=torch.float32, device=device)
+    x -= c(min)
+    x /= c(np.float32(np.float32(max) - np.float32(min)))
+    x *= c(scale_max - scale_min)
+    x += c(scale_min)
+    return x, {"dtype": dtype, "min": min, "max": max, "normalized_min": x.min().item(), "normalized_max": x.max().item()}
+
+
 def invnormalize_data(data, sideinfos, name):
     """utils/io.py:114-214 (data: torch tensor, modified in place like the reference)"""
     dtype = sideinfos["dtype"]

@@ -20,6 +20,19 @@ def parse_checkpoints(checkpoints, max_steps):
     return [int(s) for s in checkpoints.split(",") if int(s) < max_steps] + [max_steps]
 
 
+def weight_is_unit(weight_type_list):
+    """True when parse_weight() must return all ones whatever the data holds: only 'none' and 'value_l_h_s' entries with
+    s == 1 (the shipped YAMLs: 'value_65535_65535_1').  Lets the caller skip building (and scanning) a volume-sized map."""
+    for spec in weight_type_list:
+        if spec == "none":
+            continue
+        if "quantile" in spec or "exp" in spec or "value" not in spec:
+            return False
+        if float(spec.split("_")[3]) != 1.0:
+            return False
+    return True
+
+
 def parse_weight(data, weight_type_list):
     """utils/misc.py:272-307: per-voxel loss weights from 'value_l_h_s' / 'quantile_t_ql_qh_s' / 'exp_x_v' / 'none'"""
     data = np.asarray(data)

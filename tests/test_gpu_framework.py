@@ -557,3 +557,24 @@ def test_adaptive_octree_device_statistics_choose_the_pinned_partition():
     fa = np.array([n.feature for n in nodes_a if not n.pruned]); fb = np.array([n.feature for n in nodes_b if not n.pruned])
     assert np.max(np.abs(fa - fb) / np.abs(fa)) < 1e-9
     assert trees[None][1] == trees["cuda"][1] and abs(trees[None][2] - trees["cuda"][2]) <= 1e-9 * abs(trees[None][2])
+
+
+def test_device_normalisation_is_bit_identical_to_the_host_rule():
+    """io.normalize_data_device (what NFGR.prepare_fit uses) against io.normalize_data (utils/io.py:65-80, pinned to the
+    reference's goldens by tests/test_oracle_golden.py): same bits, same side information, for uint16 / uint8 / float32 data
+    and for a rule that keeps the host path"""
+    from brief_pytorch_amd.io import normalize_data, normalize_data_device
+    from brief_pytorch_amd.misc import weight_is_unit
+    from brief_pytorch_amd.synthetic import make_volume
+    rng = np.random.default_rng(3)
+    cases = [("minmaxany_0_100", make_volume((24, 40, 56), seed=4)),
+             ("minmaxany_-1_1", (rng.integers(3, 250, size=(33, 47, 3))).astype(np.uint8)),
+             ("minmaxany_0_100", rng.normal(5.0, 3.0, size=(8, 16, 16, 1)).astype(np.float32)),
+             ("minmax01_0mean", make_volume((8, 16, 16), seed=5))]
+    for name, data in cases:
+        host, side_h = normalize_data(data, name)
+        dev, side_d = normalize_data_device(data, name, "cuda")
+        assert dev.is_cuda and dev.dtype == torch.float32 and torch.equal(dev.cpu(), host), name
+        assert side_h.keys() == side_d.keys() and all(side_h[k] == side_d[k] for k in side_h), (name, side_h, side_d)
+    assert weight_is_unit(["value_65535_65535_1"]) and weight_is_unit(["none"]) and weight_is_unit([])
+    assert not weight_is_unit(["value_0_100_2"]) and not weight_is_unit(["exp_100_0.5"]) and not weight_is_unit(["quantile_0_0.1_0.9_3"])
