@@ -1541,9 +1541,13 @@ __global__ __launch_bounds__(1024) void k_reduce(const ReduceArgs a, int nb_hidd
                 const int o = (int)(r / F), i = (int)(r % F);
                 // the same products as k_repack's, bit for bit (brief_layout.h: what the copies carry)
                 const float pf = brief_phase_scale(d, l) * pv, pb = brief_om_prev(d, l) * pv;
-                blk[frag_index(NT, o, i)] = pf;                               // A-fragments of s_l W
-                blk[(int64_t)FP * FP + frag_index(NT, i, o)] = pb;            // A-fragments of w0_{l-1} W^T
-                if (d.precision == BRIEF_PREC_BF16) {
+                if (d.precision != BRIEF_PREC_BF16) {
+                    blk[frag_index(NT, o, i)] = pf;                               // A-fragments of s_l W
+                    blk[(int64_t)FP * FP + frag_index(NT, i, o)] = pb;            // A-fragments of w0_{l-1} W^T
+                } else {
+                    // the bf16 kernels read only the bf16 fragments below (and the f32 first layer, biases and head): the f32
+                    // hidden fragment slots hold zeros (k_repack) and are never read in this mode — two scattered 4-byte stores
+                    // per parameter less
                     __bf16 *b16 = reinterpret_cast<__bf16 *>(a.pk + brief_pk16_off(d, l));
                     b16[brief_frag16_index(NT, o, i)] = (__bf16)pf;
                     b16[(int64_t)FP * FP + brief_frag16_index(NT, i, o)] = (__bf16)pb;
@@ -1664,7 +1668,8 @@ __global__ void k_repack(const brief_siren_desc d, const float *__restrict__ par
             const int kt = (int)((r >> 10) % NT), mt = (int)((r >> 10) / NT);
             const int row = 32 * mt + (lanei & 31);
             const int col = 32 * kt + 8 * q + 4 * (lanei >> 5) + jj;
-            if (row < F && col < F) v = bwd ? brief_om_prev(d, l) * W[(int64_t)col * F + row] : brief_phase_scale(d, l) * W[(int64_t)row * F + col];
+            // (bf16 mode: the hidden GEMMs read the bf16 fragments only; these f32 slots stay zero, here and in k_reduce's write-through)
+            if (row < F && col < F && d.precision != BRIEF_PREC_BF16) v = bwd ? brief_om_prev(d, l) * W[(int64_t)col * F + row] : brief_phase_scale(d, l) * W[(int64_t)row * F + col];
         } else {
             const int f = (int)(r - 2 * (int64_t)FP * FP);
             if (f < F) v = brief_phase_scale(d, l) * b[f];
