@@ -196,3 +196,33 @@ def test_c4_shaped_dividetask_through_compress_divide():
     assert out["decoded_shape"] == [512, 512, 512, 1]
     assert out["perf"]["psnr"] > 24 and 0.5 < out["perf"]["ssim"] <= 1.0
     assert out["fit_voxels_per_s"] > 2e7
+
+
+def test_c2_full_size_trace_against_the_oracle_loop():
+    """BASELINE config 2 at its size over 24 optimizer steps: 256^3 volume, 4x256 SIREN, 100 000 randompoint samples per step,
+    Adamax — brief_siren_fit (in-kernel Philox sampling, fused optimizer, write-through) against the oracle's loop on the index
+    stream brief_sample_indices writes.  Loss trace <= 1e-4, parameters after the last step <= 1e-4 of their max-abs."""
+    import ctypes as C
+    dims, L, F = (256, 256, 256), 5, 256
+    steps = 24
+    m, p0, tgt, _, _, _ = _full_size_case(L, F, dims, seed=13)
+    pop = tgt.shape[0]
+    fit = Fitter(m, tgt, dims, sampler="randompoint", sample_size=N, optimizer="Adamax", lr=1e-3, seed=77,
+                 scheduler={"name": "MultiStepLR", "milestones": [50000, 60000, 70000], "gamma": 0.2})
+    trace = fit.run(steps, log=True).cpu().numpy().astype(np.float64)
+    d = O.make_desc(3, 1, L, F, 20.0)
+    p, s1, s2 = p0.copy(), np.zeros_like(p0), np.zeros_like(p0)
+    tgt_h = tgt.cpu().numpy()
+    idx = torch.empty(N, dtype=torch.int64, device="cuda")
+    ref = []
+    for t in range(1, steps + 1):
+        _lib.check(_lib.lib().brief_sample_indices(_lib.ptr(idx), N, pop, 77, t, _lib.stream_ptr()))
+        ih = idx.cpu().numpy()
+        lo, g, _, _ = O.loss_grad(d, p, O.grid_coords(dims, idx=ih), tgt_h[ih])
+        O.optim_step("Adamax", p, g, s1, s2, 1e-3, t)
+        ref.append(lo)
+    ref = np.asarray(ref)
+    err = np.abs(trace - ref) / ref
+    perr = float(np.max(np.abs(m.params.cpu().numpy() - p)) / np.max(np.abs(p)))
+    print("C2 full size, %d steps: loss %.4f -> %.4f, trace error max %.2e, parameters %.2e" % (steps, ref[0], ref[-1], err.max(), perr))
+    assert err.max() < 1e-4 and perr < 1e-4

@@ -29,7 +29,7 @@ for i, nme in enumerate(names):
     v = st[tot > 0, i]
     print('%-36s mean %9.0f cycles  %5.1f%%   (min %9.0f max %9.0f)' % (nme, v.mean(), 100 * v.mean() / tot[tot > 0].mean(), v.min(), v.max()))
 # ---- wgrad stamps
-rec_floats = 256 * 4 * 4 * 1056
+rec_floats = 256 * 8 * 4 * 1056
 ws = m._ws[rec_off + rec_floats - 256 * 8 * 8: rec_off + rec_floats].view(256, 8, 8).cpu().numpy()
 w = ws[:255].reshape(-1, 8)[:, :4]
 tot = w.sum(1)
