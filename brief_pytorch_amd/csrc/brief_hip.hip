@@ -303,8 +303,12 @@ struct FusedLds {
 #else
 #define STAMP(slot)
 #endif
+// resident TRAIN workgroups per CU: widths up to 4 tiles need <= 168 registers and run THREE (a third independent wave per SIMD
+// fills what two leave idle: 5x128 0.325 -> 0.309 ms per step, 5x96 0.293 -> 0.267; tools/ab_wpe.py); 5-8 tiles need ~210-230
+// registers: two (forced to 168 they spill 43 registers and lose 1.6 %); above: one 512-register workgroup
+constexpr int fused_train_wpe(int NT) { return NT > 8 ? 1 : (NT <= 4 ? (BRIEF_TRAIN_WPE > 3 ? BRIEF_TRAIN_WPE : 3) : BRIEF_TRAIN_WPE); }
 template <int NT, bool TRAIN>
-__global__ __launch_bounds__(256, TRAIN ? (NT > 8 ? 1 : BRIEF_TRAIN_WPE) : (NT > 8 ? 2 : 3)) void k_fused(const FusedArgs a)
+__global__ __launch_bounds__(256, TRAIN ? fused_train_wpe(NT) : (NT > 8 ? 2 : 3)) void k_fused(const FusedArgs a)
 {
 #ifdef BRIEF_STAMPS
     float st_acc[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -1895,16 +1899,18 @@ static int env_int(const char *name, int dflt, int lo, int hi)
 }
 static const int kRecWgsPerCu = 8;      // per-workgroup record slots per CU in the workspace (k_fused: body + single-tile tail)
 static const int g_wg_per_cu = env_int("BRIEF_WG_PER_CU", BRIEF_TRAIN_WPE, 1, 4);
+static const bool g_wg_per_cu_set = getenv("BRIEF_WG_PER_CU") != nullptr;
 static const int g_stagger = env_int("BRIEF_STAGGER", 1, 0, 64);
 static const int g_diag = env_int("BRIEF_DIAG", 0, 0, 255);
 static const int g_reduce_sg_big = env_int("BRIEF_REDUCE_SG_BIG", 4, 1, 64);
 static const int g_reduce_sg_small = env_int("BRIEF_REDUCE_SG", 0, 0, 64);      // diagnostics: k_reduce threads per hidden parameter behind k_small (power of two; 0 = by slab count)
 static int fused_grid(const brief_siren_desc &d, int64_t n, bool train)
 {
-    (void)train;
     const int nt = brief_nt(d);
     const int64_t tiles = (n + brief_wg_samples(nt) - 1) / brief_wg_samples(nt);
-    const int64_t cap = (int64_t)kCUs * (nt > 8 ? 1 : g_wg_per_cu);      // >8 tiles: 512-register kernel, one workgroup per CU
+    // resident workgroups per CU = what the kernel's launch bounds were compiled for (BRIEF_WG_PER_CU: diagnostics)
+    const int wpe = g_wg_per_cu_set ? g_wg_per_cu : (train ? fused_train_wpe(nt) : (nt > 8 ? 2 : 3));
+    const int64_t cap = (int64_t)kCUs * (train && nt > 8 ? 1 : wpe);      // TRAIN > 8 tiles: 512-register kernel, one workgroup per CU
     return (int)(tiles < cap ? (tiles > 0 ? tiles : 1) : cap);
 }
 // k_fused<TRAIN> launch plan: a persistent body of `cap` workgroups over whole rounds of tiles, the rest of the batch
