@@ -304,9 +304,17 @@ struct FusedLds {
 #define STAMP(slot)
 #endif
 // resident TRAIN workgroups per CU: widths up to 4 tiles need <= 168 registers and run THREE (a third independent wave per SIMD
-// fills what two leave idle: 5x128 0.325 -> 0.309 ms per step, 5x96 0.293 -> 0.267; tools/ab_wpe.py); 5-8 tiles need ~210-230
-// registers: two (forced to 168 they spill 43 registers and lose 1.6 %); above: one 512-register workgroup
-constexpr int fused_train_wpe(int NT) { return NT > 8 ? 1 : (NT <= 4 ? (BRIEF_TRAIN_WPE > 3 ? BRIEF_TRAIN_WPE : 3) : BRIEF_TRAIN_WPE); }
+// fills what two leave idle: 5x128 0.325 -> 0.309 ms per step, 5x96 0.293 -> 0.267; tools/ab_wpe.py); 5-7 tiles need ~220-230
+// registers: two (forced to 168 they spill ~40 registers and lose 1.6 %); above 8: one 512-register workgroup
+// The 8-tile kernel (F = 225 ... 256, the headline) runs THREE workgroups per CU as well, in a lean form: it gives up the two
+// register sets it parked across phases (the next layer's bias during an epilogue, the previous layer's phases during a dgrad
+// chain: 64 registers; their latency is now covered by the two other waves of the SIMD) and fits 168 registers with one spilled
+// dword: k_fused 0.680 -> 0.667 ms, 99.2 -> 100.1 M voxels/s (tools/ab_c2.sh).  5-7 tiles spill 36-46 registers in that form: two.
+#ifndef BRIEF_LEAN
+#define BRIEF_LEAN 1
+#endif
+constexpr bool fused_lean(int NT) { return BRIEF_LEAN && NT == 8; }
+constexpr int fused_train_wpe(int NT) { return NT > 8 ? 1 : (NT <= 4 || fused_lean(NT) ? (BRIEF_TRAIN_WPE > 3 ? BRIEF_TRAIN_WPE : 3) : BRIEF_TRAIN_WPE); }
 template <int NT, bool TRAIN>
 __global__ __launch_bounds__(256, TRAIN ? fused_train_wpe(NT) : (NT > 8 ? 2 : 3)) void k_fused(const FusedArgs a)
 {
@@ -467,6 +475,7 @@ __global__ __launch_bounds__(256, TRAIN ? fused_train_wpe(NT) : (NT > 8 ? 2 : 3)
         for (int l = 0; l <= L - 2; ++l) {
             const bool last = (l == L - 2);
             if (l > 0) {
+                if (TRAIN && fused_lean(NT)) FUSED_LOAD_BIAS(l)      // lean variant: no register set parked across the epilogue
 #pragma unroll
                 for (int t = 0; t < K::MTW; ++t) {
 #pragma unroll
@@ -484,7 +493,7 @@ __global__ __launch_bounds__(256, TRAIN ? fused_train_wpe(NT) : (NT > 8 ? 2 : 3)
                 lds_barrier();   // every wave is done reading the previous image
                 STAMP(2)
             }
-            if (!last) FUSED_LOAD_BIAS(l + 1)   // lands while this epilogue computes its sines
+            if (!last && !(TRAIN && fused_lean(NT))) FUSED_LOAD_BIAS(l + 1)   // lands while this epilogue computes its sines
             // epilogue: stash z, h = sin(om z) (+ c = om cos(om z) on the last sine layer)
 #pragma unroll
             for (int t = 0; t < K::MTW; ++t) {
@@ -679,15 +688,16 @@ __global__ __launch_bounds__(256, TRAIN ? fused_train_wpe(NT) : (NT > 8 ? 2 : 3)
             const __amdgpu_buffer_rsrc_t rzp =
                 __builtin_amdgcn_make_buffer_rsrc((void *)(a.Z + (int64_t)(l - 1) * K::FP * npad), 0, stash_bytes, 0x00020000);
             float zr[K::MTW][16];
-#pragma unroll
-            for (int t = 0; t < K::MTW; ++t) {
-                const int mt = wm + K::WM * t;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    zr[t][r] = 0.f;
-                    if (K::EXACT || mt < NT) zr[t][r] = bload1(rzp, voff_s, (32 * mt + (r & 3) + 8 * (r >> 2)) * rbd);
-                }
-            }
+            constexpr bool ZPRE = !fused_lean(NT);      // lean variant: the phases are fetched after the chain (two other waves cover the latency)
+#define FUSED_LOAD_Z()                                                                                  \
+    _Pragma("unroll") for (int t = 0; t < K::MTW; ++t) {                                                \
+        const int mt = wm + K::WM * t;                                                                  \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                \
+            zr[t][r] = 0.f;                                                                             \
+            if (K::EXACT || mt < NT) zr[t][r] = bload1(rzp, voff_s, (32 * mt + (r & 3) + 8 * (r >> 2)) * rbd); \
+        }                                                                                               \
+    }
+            if (ZPRE) FUSED_LOAD_Z()
             STAMP(7)
             lds_barrier();   // transpose scratch / previous chain finished with the image region
             write_image<NT>(Xs, dl, wm, lane);
@@ -701,6 +711,8 @@ __global__ __launch_bounds__(256, TRAIN ? fused_train_wpe(NT) : (NT > 8 ? 2 : 3)
             chain<NT>(acc, rs_pk, (int)((brief_pk_hidden(d, l) + K::FP * K::FP) * 4), Xs, wm, lane, kit);
             __builtin_amdgcn_s_setprio(0);
             STAMP(9)
+            if (!ZPRE) FUSED_LOAD_Z()
+#undef FUSED_LOAD_Z
             // delta_{l-1} = acc * cos(phase_{l-1}): the chain ran on w0_{l-1} W_l^T, the stash holds the phase in revolutions
 #pragma unroll
             for (int t = 0; t < K::MTW; ++t) {
