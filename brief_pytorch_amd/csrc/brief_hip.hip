@@ -1912,7 +1912,7 @@ static int env_int(const char *name, int dflt, int lo, int hi)
 static const int kRecWgsPerCu = 8;      // per-workgroup record slots per CU in the workspace (k_fused: body + single-tile tail)
 static const int g_wg_per_cu = env_int("BRIEF_WG_PER_CU", BRIEF_TRAIN_WPE, 1, 4);
 static const bool g_wg_per_cu_set = getenv("BRIEF_WG_PER_CU") != nullptr;
-static const int g_stagger = env_int("BRIEF_STAGGER", 1, 0, 64);
+static const int g_stagger = env_int("BRIEF_STAGGER", 0, 0, 64);      // start delay per residency slot: measured neutral with two and with three workgroups per CU (profiles/r03_wg_timeline.md), off
 static const int g_diag = env_int("BRIEF_DIAG", 0, 0, 255);
 static const int g_reduce_sg_big = env_int("BRIEF_REDUCE_SG_BIG", 4, 1, 64);
 static const int g_reduce_sg_small = env_int("BRIEF_REDUCE_SG", 0, 0, 64);      // diagnostics: k_reduce threads per hidden parameter behind k_small (power of two; 0 = by slab count)
