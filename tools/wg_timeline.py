@@ -8,13 +8,14 @@ from brief_pytorch_amd.networks import SIREN
 from brief_pytorch_amd.fit import Fitter
 torch.manual_seed(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
-tr = int(os.environ.get("BRIEF_TAIL_ROUNDS", "1"))
+tr = int(os.environ.get("BRIEF_TAIL_ROUNDS", "0"))
 m = SIREN(features=256, layers=5, w0=20).to('cuda')
 tv = torch.rand(256 ** 3, 1, device='cuda') * 100
 fit = Fitter(m, tv, (256, 256, 256), sample_size=n)
 for _ in range(600): fit.step()
 torch.cuda.synchronize()
-FP, hidden, cap = 256, 3, 512
+FP, hidden = 256, 3
+cap = 256 * int(os.environ.get("BRIEF_WG_PER_CU", "3"))      # resident workgroups (round 3: three per CU for the lean 8-tile kernel)
 npad = (n + 31) // 32 * 32
 ntiles = (n + 31) // 32
 rounds = max(ntiles // cap - tr, 0) if tr > 0 else None
@@ -32,7 +33,7 @@ print('n=%d tail_rounds=%d: grid %d (persistent %d over %d tiles, %d single-tile
 def cls(name, k):
     if k.sum(): print('  %-28s %4d wgs: start mean %6.1f (%6.1f..%6.1f)  life mean %6.1f (%6.1f..%6.1f)  end mean %6.1f max %6.1f' % (name, k.sum(), start[k].mean(), start[k].min(), start[k].max(), life[k].mean(), life[k].min(), life[k].max(), end[k].mean(), end[k].max()))
 b = np.arange(grid)
-cls('persistent, first slot', (b < 256) & (b < pers)); cls('persistent, second slot', (b >= 256) & (b < pers))
+for q in range(0, pers, 256): cls('persistent, slot %d' % (q // 256), (b >= q) & (b < q + 256) & (b < pers))
 for q in range(0, max(grid - pers, 0), 256): cls('single-tile %d..%d' % (q, min(q + 256, grid - pers) - 1), (b >= pers + q) & (b < pers + q + 256))
 h, e = np.histogram(end, bins=12)
 print('  end-time histogram: ' + ' '.join('%.0f:%d' % (e[i + 1], h[i]) for i in range(len(h))))
