@@ -48,7 +48,7 @@ class FitJob(C.Structure):          # brief_fit_job
 LOSS_KIND = {"datal2": 0, "datasmoothl1": 1, "external": 2}
 OPT_KIND = {"Adamax": 0, "Adam": 1, "SGD": 2}
 OUT_F32, OUT_U8, OUT_U16 = 0, 1, 2
-PRECISION = {"fp32": 0, "f32": 0, "bf16": 1}
+PRECISION = {"fp32": 0, "f32": 0, "bf16": 1, "bf16x3": 2}
 
 EXPORTS = ["brief_version", "brief_last_error", "brief_param_count", "brief_packed_count",
            "brief_train_workspace_bytes", "brief_siren_repack", "brief_siren_forward", "brief_siren_train_step", "brief_siren_fit_step",

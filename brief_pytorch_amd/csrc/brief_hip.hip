@@ -257,6 +257,105 @@ __device__ __forceinline__ void write_image(float4 *Xs, const f32x16 (&h)[KCfg<N
 }
 
 // ---------------------------------------------------------------------------------------------
+// BRIEF_PREC_BF16X3: split-precision hidden GEMMs.  x = hi + lo with hi = bf16(x), lo = bf16(x - hi) keeps ~16 significant bits
+// of x; a product of two such operands is hi.hi + hi.lo + lo.hi (the dropped lo.lo term is 2^-16 of the product), three
+// v_mfma_f32_32x32x16_bf16 with f32 accumulation where the exact path issues eight v_mfma_f32_32x32x2_f32: 96 instead of 512
+// matrix-pipe cycles per 32 x 32 x 16 block.  tools/bf16x3_emulation.py: forward 7.9e-6 of max|y| and gradients 1.0e-5 of a
+// tensor's max-abs against float64 on the 4x256 net (f32: 7e-7 / 4e-7; bands 2e-5 / 1e-4).  Same skeleton as the f32 path (32-sample
+// tiles, f32 stashes, f32 head / loss / skinny gradients / optimizer); only the image and the weight fragments change.
+typedef __bf16 x3_bf16x8 __attribute__((ext_vector_type(8)));
+union X3Frag { uint4 u; x3_bf16x8 v; };
+#define MFMA_X3(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+// registers 8s .. 8s+7 of an accumulator tile -> the hi and lo bf16 fragments of k-step s (the next layer's B operand)
+__device__ __forceinline__ void x3_pack(const f32x16 &x, int s, uint4 &hi, uint4 &lo)
+{
+    X3Frag h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 b = (__bf16)x[8 * s + j];
+        h.v[j] = b;
+        l.v[j] = (__bf16)(x[8 * s + j] - (float)b);
+    }
+    hi = h.u; lo = l.u;
+}
+
+// image layout: [hi | lo][kt][s][lane] x 16 B  (NT * 2 * 64 uint4 per half)
+template <int NT>
+__device__ __forceinline__ void x3_write_image(uint4 *X16, const f32x16 (&h)[KCfg<NT>::MTW], int wm, int lane)
+{
+    using K = KCfg<NT>;
+#pragma unroll
+    for (int t = 0; t < K::MTW; ++t) {
+        const int mt = wm + K::WM * t;
+        if (K::EXACT || mt < NT) {
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx) {
+                uint4 hi, lo;
+                x3_pack(h[t], sx, hi, lo);
+                X16[(mt * 2 + sx) * 64 + lane] = hi;
+                X16[NT * 2 * 64 + (mt * 2 + sx) * 64 + lane] = lo;
+            }
+        }
+    }
+}
+
+// one layer's GEMM for the feature tiles this wave owns, three bf16 MFMAs per (A, B) fragment pair.
+// rs: descriptor over the hi | lo fragment regions; soff_layer: byte offset of the layer's Wf16 (or Wb16) block in the hi
+// region; lo_bytes: distance to the same block in the lo region.  kit: k-steps (of 16 features) that hold real features.
+template <int NT>
+__device__ __forceinline__ void x3_chain(f32x16 (&acc)[KCfg<NT>::MTW], __amdgpu_buffer_rsrc_t rs, int soff_layer, int lo_bytes,
+                                         const uint4 *X16, int wm, int lane, int kit)
+{
+    using K = KCfg<NT>;
+    constexpr int NIT = NT * 2;
+    constexpr int PD = 2;
+    const int voff = lane * 16;
+    int soff_w = soff_layer + wm * (NT * 2 * 1024);
+    asm volatile("" : "+s"(soff_w));
+    int soff_lo = lo_bytes;
+    asm volatile("" : "+s"(soff_lo));
+    uint4 ahi[NIT][K::MTW], alo[NIT][K::MTW];
+    uint4 bhi[NIT], blo[NIT];
+#define X3_LOAD(it_)                                                                                         \
+    _Pragma("unroll") for (int t = 0; t < K::MTW; ++t) {                                                     \
+        if (K::EXACT || wm + K::WM * t < NT) {                                                               \
+            const u32x4 vh = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff_w + (K::WM * t * NT * 2 + (it_)) * 1024, 0); \
+            const u32x4 vl = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff_w + soff_lo + (K::WM * t * NT * 2 + (it_)) * 1024, 0); \
+            ahi[it_][t] = make_uint4(vh.x, vh.y, vh.z, vh.w);                                                \
+            alo[it_][t] = make_uint4(vl.x, vl.y, vl.z, vl.w);                                                \
+        }                                                                                                    \
+    }
+#pragma unroll
+    for (int it = 0; it < PD; ++it)
+        if (it < kit) X3_LOAD(it)
+    bhi[0] = X16[lane]; blo[0] = X16[NT * 2 * 64 + lane];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        // (no early exit: a runtime `break` keeps hipcc from unrolling, and the fragment arrays then live in scratch; the steps
+        //  above kit — zero weight columns against zero activations — are skipped by wave-uniform branches instead)
+        if (it + PD < NIT && it + PD < kit) X3_LOAD(it + PD)
+        if (it + 1 < NIT && it + 1 < kit) { bhi[it + 1] = X16[(it + 1) * 64 + lane]; blo[it + 1] = X16[NT * 2 * 64 + (it + 1) * 64 + lane]; }
+        __builtin_amdgcn_sched_barrier(0);
+        if (it < kit) {
+            X3Frag fbh, fbl;
+            fbh.u = bhi[it]; fbl.u = blo[it];
+#pragma unroll
+            for (int t = 0; t < K::MTW; ++t) {
+                if (K::EXACT || wm + K::WM * t < NT) {
+                    X3Frag fah, fal;
+                    fah.u = ahi[it][t]; fal.u = alo[it][t];
+                    acc[t] = MFMA_X3(fah.v, fbh.v, acc[t]);
+                    acc[t] = MFMA_X3(fah.v, fbl.v, acc[t]);
+                    acc[t] = MFMA_X3(fal.v, fbh.v, acc[t]);
+                }
+            }
+        }
+    }
+#undef X3_LOAD
+}
+
+// ---------------------------------------------------------------------------------------------
 // Philox4x32-10 voxel-index stream (stands in for the CPU torch.randint of main.py:156)
 __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1)
 {
@@ -315,8 +414,8 @@ struct FusedLds {
 #endif
 constexpr bool fused_lean(int NT) { return BRIEF_LEAN && NT == 8; }
 constexpr int fused_train_wpe(int NT) { return NT > 8 ? 1 : (NT <= 4 || fused_lean(NT) ? (BRIEF_TRAIN_WPE > 3 ? BRIEF_TRAIN_WPE : 3) : BRIEF_TRAIN_WPE); }
-template <int NT, bool TRAIN>
-__global__ __launch_bounds__(256, TRAIN ? fused_train_wpe(NT) : (NT > 8 ? 2 : 3)) void k_fused(const FusedArgs a)
+template <int NT, bool TRAIN, int PREC = 0 /* 0: f32 MFMA; 2: BRIEF_PREC_BF16X3 hidden GEMMs (x3_chain) */>
+__global__ __launch_bounds__(256, TRAIN ? (PREC == 2 ? 2 : fused_train_wpe(NT)) : (NT > 8 ? 2 : 3)) void k_fused(const FusedArgs a)
 {
 #ifdef BRIEF_STAMPS
     float st_acc[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -330,6 +429,13 @@ __global__ __launch_bounds__(256, TRAIN ? fused_train_wpe(NT) : (NT > 8 ? 2 : 3)
     float *T = smem;                       // aliases X
     float *G = smem + LD::G_OFF;
     float *HW = smem + LD::HW_OFF;         // Whp[4][FP], bhp[4]
+    uint4 *X16 = reinterpret_cast<uint4 *>(smem);      // PREC == 2: the image as hi | lo bf16 fragments (same bytes as the f32 image)
+    float4 *PART = reinterpret_cast<float4 *>(smem + LD::TOTAL);      // PREC == 2: head partials [4 waves][32 samples] (launch adds 2 KB)
+    const int kit16 = (a.d.features + 15) >> 4;
+    const __amdgpu_buffer_rsrc_t rs_x3 = PREC == 2
+        ? __builtin_amdgcn_make_buffer_rsrc((void *)(a.pk + brief_pk16_off(a.d, 1)), 0, (int)(2 * brief_pk16_region(a.d) * 4), 0x00020000)
+        : __builtin_amdgcn_make_buffer_rsrc((void *)a.pk, 0, 16, 0x00020000);
+    const int x3_lo_bytes = (int)(brief_pk16_region(a.d) * 4);
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -487,7 +593,8 @@ __global__ __launch_bounds__(256, TRAIN ? fused_train_wpe(NT) : (NT > 8 ? 2 : 3)
                 // matrix work first: the wave inside a chain outranks its SIMD mate's epilogue (-0.5 % step time; the opposite
                 // order, epilogues first, costs +0.5 %: tools/ab_lib.sh, profiles/r02_issue_model.md)
                 if (TRAIN) __builtin_amdgcn_s_setprio(3);
-                chain<NT>(acc, rs_pk, (int)(brief_pk_hidden(d, l) * 4), Xs, wm, lane, kit);
+                if constexpr (PREC == 2) x3_chain<NT>(acc, rs_x3, (l - 1) * K::FP * K::FP * 4, x3_lo_bytes, X16, wm, lane, kit16);
+                else chain<NT>(acc, rs_pk, (int)(brief_pk_hidden(d, l) * 4), Xs, wm, lane, kit);
                 if (TRAIN) __builtin_amdgcn_s_setprio(0);
                 STAMP(1)
                 lds_barrier();   // every wave is done reading the previous image
@@ -529,7 +636,8 @@ __global__ __launch_bounds__(256, TRAIN ? fused_train_wpe(NT) : (NT > 8 ? 2 : 3)
                     }
                 }
             }
-            write_image<NT>(Xs, hreg, wm, lane);
+            if constexpr (PREC == 2) x3_write_image<NT>(X16, hreg, wm, lane);
+            else write_image<NT>(Xs, hreg, wm, lane);
             STAMP(3)
             lds_barrier();
             STAMP(4)
@@ -539,7 +647,7 @@ __global__ __launch_bounds__(256, TRAIN ? fused_train_wpe(NT) : (NT > 8 ? 2 : 3)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             zo[c] = 0.f; yh[c] = 0.f; g[c] = 0.f;
-            if (c < cout) {
+            if (c < cout && PREC != 2) {
                 float p = 0.f;
                 const float *wrow = HW + c * K::FP;
 #pragma unroll
@@ -555,6 +663,45 @@ __global__ __launch_bounds__(256, TRAIN ? fused_train_wpe(NT) : (NT > 8 ? 2 : 3)
                 p += __shfl_xor(p, 32);
                 zo[c] = p + HW[4 * K::FP + c];
                 yh[c] = d.output_act ? brief_fast_sinf(d.w0_hidden * zo[c]) : zo[c];
+            }
+        }
+        if constexpr (PREC == 2) {
+            // the image holds bf16 halves: the head is taken from the exact f32 activations instead — every wave's partial dot
+            // product over the features it owns, summed over the four waves through LDS in wave order
+            float pp[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (c < cout) {
+#pragma unroll
+                    for (int t = 0; t < K::MTW; ++t) {
+                        const int mt = wm + K::WM * t;
+                        if (K::EXACT || mt < NT) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float4 wv = *reinterpret_cast<const float4 *>(HW + c * K::FP + 32 * mt + 8 * q + 4 * hi);
+                                pp[c] = __fmaf_rn(wv.x, hreg[t][4 * q], pp[c]); pp[c] = __fmaf_rn(wv.y, hreg[t][4 * q + 1], pp[c]);
+                                pp[c] = __fmaf_rn(wv.z, hreg[t][4 * q + 2], pp[c]); pp[c] = __fmaf_rn(wv.w, hreg[t][4 * q + 3], pp[c]);
+                            }
+                        }
+                    }
+                    pp[c] += __shfl_xor(pp[c], 32);
+                }
+            }
+            if (hi == 0) PART[wave * 32 + ln] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+            lds_barrier();
+            float4 tot = PART[ws * K::WM * 32 + ln];
+#pragma unroll
+            for (int w = 1; w < K::WM; ++w) {
+                const float4 v = PART[(ws * K::WM + w) * 32 + ln];
+                tot.x += v.x; tot.y += v.y; tot.z += v.z; tot.w += v.w;
+            }
+            const float tt[4] = {tot.x, tot.y, tot.z, tot.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (c < cout) {
+                    zo[c] = tt[c] + HW[4 * K::FP + c];
+                    yh[c] = d.output_act ? brief_fast_sinf(d.w0_hidden * zo[c]) : zo[c];
+                }
             }
         }
         if (!TRAIN) {
@@ -700,7 +847,8 @@ __global__ __launch_bounds__(256, TRAIN ? fused_train_wpe(NT) : (NT > 8 ? 2 : 3)
             if (ZPRE) FUSED_LOAD_Z()
             STAMP(7)
             lds_barrier();   // transpose scratch / previous chain finished with the image region
-            write_image<NT>(Xs, dl, wm, lane);
+            if constexpr (PREC == 2) x3_write_image<NT>(X16, dl, wm, lane);
+            else write_image<NT>(Xs, dl, wm, lane);
             lds_barrier();
             STAMP(8)
 #pragma unroll
@@ -708,7 +856,8 @@ __global__ __launch_bounds__(256, TRAIN ? fused_train_wpe(NT) : (NT > 8 ? 2 : 3)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
             __builtin_amdgcn_s_setprio(3);
-            chain<NT>(acc, rs_pk, (int)((brief_pk_hidden(d, l) + K::FP * K::FP) * 4), Xs, wm, lane, kit);
+            if constexpr (PREC == 2) x3_chain<NT>(acc, rs_x3, (l - 1) * K::FP * K::FP * 4 + K::FP * K::FP * 2, x3_lo_bytes, X16, wm, lane, kit16);
+            else chain<NT>(acc, rs_pk, (int)((brief_pk_hidden(d, l) + K::FP * K::FP) * 4), Xs, wm, lane, kit);
             __builtin_amdgcn_s_setprio(0);
             STAMP(9)
             if (!ZPRE) FUSED_LOAD_Z()
@@ -1444,6 +1593,141 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
+// BRIEF_PREC_BF16X3 weight-gradient GEMM (FP = 256): the same split-K job as k_wgrad<8> on the same f32 stashes, with both
+// operands split into hi + lo bf16 halves while they are staged (h = sin(2 pi phase) first) and three v_mfma_f32_32x32x16_bf16
+// per fragment pair.  Panel rows are [32 samples hi | 32 samples lo | pad] = 144 B, the f32 kernel's conflict-free 36-dword
+// stride; a fragment is 16 B of a row (8 consecutive samples).  Bias gradients: row sums of the f32 deltas, taken by the threads
+// that stage them.  Same slab format as k_wgrad: k_reduce does not know the difference.
+__global__ __launch_bounds__(512, 2) void k_wgrad_x3(const WgradArgs a)
+{
+    constexpr int FP = 256, QT = 8, WNk = 4, TM = 4, TN = 2, LDSW = 36, NLD = 4, PANEL = FP * LDSW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2 buffers][A panel | B panel]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, ln = lane & 31;
+    const int wmk = wave / WNk, wnk = wave % WNk;
+    const int l = 1 + (int)blockIdx.x / a.nsplit;                  // hidden layer 1..L-2
+    const int split = (int)blockIdx.x % a.nsplit;
+    const int64_t nchunks = a.npad / 32;
+    const int64_t c0 = nchunks * split / a.nsplit, c1 = nchunks * (split + 1) / a.nsplit;
+    const float *Dl = a.D + (int64_t)(l - 1) * FP * a.npad;
+    const float *Zl = a.Z + (int64_t)(l - 1) * FP * a.npad;
+    (void)QT;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
+    float bsum[NLD] = {0.f, 0.f, 0.f, 0.f};
+    float4 ra[NLD], rb[NLD];
+    const int panel_bytes = (int)((int64_t)FP * a.npad * 4);
+    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void *)Dl, 0, panel_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc((void *)Zl, 0, panel_bytes, 0x00020000);
+    int voffs[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int e = tid + 512 * i;
+        voffs[i] = (e >> 3) * (int)(a.npad * 4) + (e & 7) * 16;
+    }
+#define X3W_ISSUE(cc)                                                                             \
+    _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                             \
+        ra[i] = bload4(rsD, voffs[i], (int)((cc) * 128));                                         \
+        rb[i] = bload4(rsZ, voffs[i], (int)((cc) * 128));                                         \
+    }
+    // four f32 values of one row -> 4 hi + 4 lo bf16 (8 + 8 bytes) in the row's hi / lo halves
+#define X3W_PUT(dst_, v_)                                                                         \
+    {                                                                                             \
+        union { uint2 u; __bf16 h[4]; } ph_, pl_;                                                 \
+        const float f_[4] = {(v_).x, (v_).y, (v_).z, (v_).w};                                     \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                        \
+            ph_.h[j_] = (__bf16)f_[j_];                                                           \
+            pl_.h[j_] = (__bf16)(f_[j_] - (float)ph_.h[j_]);                                      \
+        }                                                                                         \
+        *reinterpret_cast<uint2 *>(dst_) = ph_.u;                                                 \
+        *reinterpret_cast<uint2 *>((dst_) + 16) = pl_.u;       /* + 64 bytes: the lo half */      \
+    }
+#define X3W_STAGE(buf, count_)                                                                    \
+    _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                             \
+        const int e = tid + 512 * i;                                                              \
+        float *pa_ = smem + (buf) * 2 * PANEL + (e >> 3) * LDSW + (e & 7) * 2;                    \
+        X3W_PUT(pa_, ra[i])                                                                       \
+        if (count_) bsum[i] += (ra[i].x + ra[i].y) + (ra[i].z + ra[i].w);                         \
+        float4 h_;                                                                                \
+        h_.x = BRIEF_SIN_REV(rb[i].x); h_.y = BRIEF_SIN_REV(rb[i].y);                             \
+        h_.z = BRIEF_SIN_REV(rb[i].z); h_.w = BRIEF_SIN_REV(rb[i].w);                             \
+        X3W_PUT(pa_ + PANEL, h_)                                                                  \
+    }
+    X3W_ISSUE(c0)
+    X3W_STAGE(0, true)
+    {
+        const int64_t cn = c0 + 1 < c1 ? c0 + 1 : c1 - 1;
+        X3W_ISSUE(cn)
+    }
+    lds_barrier();
+    for (int64_t c = c0; c < c1; ++c) {
+        const int cur = (int)(c - c0) & 1;
+        const float *As = smem + cur * 2 * PANEL, *Bs = As + PANEL;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            X3Frag ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const float *p_ = As + (32 * (wmk * TM + i) + ln) * LDSW + 8 * ks + 4 * hi;      // dwords: (16 ks + 8 hi) samples x 2 B
+                ah[i].u = *reinterpret_cast<const uint4 *>(p_);
+                al[i].u = *reinterpret_cast<const uint4 *>(p_ + 16);
+            }
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) {
+                const float *p_ = Bs + (32 * (wnk * TN + jn) + ln) * LDSW + 8 * ks + 4 * hi;
+                bh[jn].u = *reinterpret_cast<const uint4 *>(p_);
+                bl[jn].u = *reinterpret_cast<const uint4 *>(p_ + 16);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn) {
+                    acc[i][jn] = MFMA_X3(ah[i].v, bh[jn].v, acc[i][jn]);
+                    acc[i][jn] = MFMA_X3(ah[i].v, bl[jn].v, acc[i][jn]);
+                    acc[i][jn] = MFMA_X3(al[i].v, bh[jn].v, acc[i][jn]);
+                }
+        }
+        // stage chunk c + 1 (its loads were issued an iteration ago), then request chunk c + 2
+        const bool fresh = c + 1 < c1;
+        X3W_STAGE(cur ^ 1, fresh)
+        {
+            const int64_t cn = c + 2 < c1 ? c + 2 : c1 - 1;
+            X3W_ISSUE(cn)
+        }
+        lds_barrier();
+    }
+#undef X3W_ISSUE
+#undef X3W_PUT
+#undef X3W_STAGE
+    float *slab = a.slabs + ((int64_t)(l - 1) * a.nsplit + split) * ((int64_t)FP * FP + FP);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int mt = wmk * TM + i;
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) {
+            const int nt = wnk * TN + jn;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) slab[(int64_t)(32 * mt + ROWMAP(r, hi)) * FP + 32 * nt + ln] = acc[i][jn][r];
+        }
+    }
+    // bias gradients: the eight threads that staged the eight 16-byte pieces of a row are neighbouring lanes
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        float v = bsum[i];
+        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+        if ((tid & 7) == 0) slab[(int64_t)FP * FP + (tid >> 3) + 64 * i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // optimizer: same arithmetic, in the same order, as oracle_optim_step (torch single-tensor rules)
 struct OptimScalars { int kind; float w1, fb2, w2, feps, nstep, bc2s; };
 
@@ -1560,7 +1844,17 @@ __global__ __launch_bounds__(1024) void k_reduce(const ReduceArgs a, int nb_hidd
                 if (d.precision != BRIEF_PREC_BF16) {
                     blk[frag_index(NT, o, i)] = pf;                               // A-fragments of s_l W
                     blk[(int64_t)FP * FP + frag_index(NT, i, o)] = pb;            // A-fragments of w0_{l-1} W^T
-                } else {
+                }
+                if (d.precision == BRIEF_PREC_BF16X3) {
+                    // hi + lo bf16 halves of the same two products (k_repack forms them the same way)
+                    __bf16 *h16 = reinterpret_cast<__bf16 *>(a.pk + brief_pk16_off(d, l));
+                    __bf16 *l16 = reinterpret_cast<__bf16 *>(a.pk + brief_pk16_off(d, l) + brief_pk16_region(d));
+                    const __bf16 fh = (__bf16)pf, bh = (__bf16)pb;
+                    h16[brief_frag16_index(NT, o, i)] = fh;
+                    h16[(int64_t)FP * FP + brief_frag16_index(NT, i, o)] = bh;
+                    l16[brief_frag16_index(NT, o, i)] = (__bf16)(pf - (float)fh);
+                    l16[(int64_t)FP * FP + brief_frag16_index(NT, i, o)] = (__bf16)(pb - (float)bh);
+                } else if (d.precision == BRIEF_PREC_BF16) {
                     // the bf16 kernels read only the bf16 fragments below (and the f32 first layer, biases and head): the f32
                     // hidden fragment slots hold zeros (k_repack) and are never read in this mode — two scattered 4-byte stores
                     // per parameter less
@@ -1643,7 +1937,9 @@ __global__ void k_repack(const brief_siren_desc d, const float *__restrict__ par
         const int64_t base16 = brief_pk16_off(d, 1);
         uint32_t word = 0;
         if (e >= base16) {
-            const int64_t rr = e - base16;
+            int64_t rr = e - base16;
+            const bool lo_half = rr >= brief_pk16_region(d);      // BRIEF_PREC_BF16X3: the second region holds bf16(w - bf16(w))
+            if (lo_half) rr -= brief_pk16_region(d);
             const int l = 1 + (int)(rr / ((int64_t)FP * FP));
             const float *W = params + brief_canon_hidden_off(d, l);
             for (int half = 0; half < 2; ++half) {
@@ -1659,6 +1955,7 @@ __global__ void k_repack(const brief_siren_desc d, const float *__restrict__ par
                 if (row < F && col < F) w = bwd ? brief_om_prev(d, l) * W[(int64_t)col * F + row] : brief_phase_scale(d, l) * W[(int64_t)row * F + col];
                 union { __bf16 h; uint16_t u; } cv;
                 cv.h = (__bf16)w;
+                if (lo_half) cv.h = (__bf16)(w - (float)cv.h);
                 word |= (uint32_t)cv.u << (16 * half);
             }
         }
@@ -1859,7 +2156,9 @@ static int check_desc(const brief_siren_desc *d)
     if (d->layers < 2) return fail(BRIEF_ERR_INVALID, "layers must be >= 2");
     if (d->features < 1 || d->features > 32 * BRIEF_MAX_NT)
         return fail(BRIEF_ERR_INVALID, "features must be 1..512 on the fused fp32 path");
-    if (d->precision != BRIEF_PREC_F32 && d->precision != BRIEF_PREC_BF16) return fail(BRIEF_ERR_INVALID, "precision must be BRIEF_PREC_F32 or BRIEF_PREC_BF16");
+    if (d->precision != BRIEF_PREC_F32 && d->precision != BRIEF_PREC_BF16 && d->precision != BRIEF_PREC_BF16X3)
+        return fail(BRIEF_ERR_INVALID, "precision must be BRIEF_PREC_F32, BRIEF_PREC_BF16 or BRIEF_PREC_BF16X3");
+    if (d->precision == BRIEF_PREC_BF16X3 && d->features > 256) return fail(BRIEF_ERR_INVALID, "BRIEF_PREC_BF16X3 supports features <= 256");
     return 0;
 }
 
@@ -1921,7 +2220,7 @@ static int fused_grid(const brief_siren_desc &d, int64_t n, bool train)
     const int nt = brief_nt(d);
     const int64_t tiles = (n + brief_wg_samples(nt) - 1) / brief_wg_samples(nt);
     // resident workgroups per CU = what the kernel's launch bounds were compiled for (BRIEF_WG_PER_CU: diagnostics)
-    const int wpe = g_wg_per_cu_set ? g_wg_per_cu : (train ? fused_train_wpe(nt) : (nt > 8 ? 2 : 3));
+    const int wpe = g_wg_per_cu_set ? g_wg_per_cu : (train ? (d.precision == BRIEF_PREC_BF16X3 ? 2 : fused_train_wpe(nt)) : (nt > 8 ? 2 : 3));
     const int64_t cap = (int64_t)kCUs * (train && nt > 8 ? 1 : wpe);      // TRAIN > 8 tiles: 512-register kernel, one workgroup per CU
     return (int)(tiles < cap ? (tiles > 0 ? tiles : 1) : cap);
 }
@@ -1965,7 +2264,7 @@ static bool use_small(const brief_siren_desc &d)
 {
     static int enabled = -1;
     if (enabled < 0) { const char *e = getenv("BRIEF_SMALL"); enabled = (e && atoi(e) == 0) ? 0 : 1; }
-    return enabled && brief_nt(d) <= 2 && d.layers - 2 <= 7;
+    return enabled && d.precision == BRIEF_PREC_F32 && brief_nt(d) <= 2 && d.layers - 2 <= 7;
 }
 static int small_hb(const brief_siren_desc &d)
 {
@@ -2094,6 +2393,18 @@ template <bool TRAIN>
 static int launch_fused(const FusedArgs &fa, int grid, hipStream_t st)
 {
     const int nt = brief_nt(fa.d);
+    if (TRAIN && fa.d.precision == BRIEF_PREC_BF16X3) {
+        // split-precision hidden GEMMs (FP = 256): the f32 kernel's skeleton with x3_chain / x3_write_image, + 2 KB of head partials
+        const size_t lds = sizeof(float) * FusedLds<8>::TOTAL + 4 * 32 * sizeof(float4);
+        static bool attr_x3 = false;
+        if (!attr_x3) {
+            HIP_TRY(hipFuncSetAttribute((const void *)k_fused<8, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_x3 = true;
+        }
+        hipLaunchKernelGGL((k_fused<8, true, 2>), dim3(grid), dim3(256), lds, st, fa);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
 #define BRIEF_CASE(NTV)                                                                                  \
     case NTV: {                                                                                          \
         const size_t lds = sizeof(float) * FusedLds<NTV>::TOTAL;                                         \
@@ -2336,6 +2647,9 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
         wa.d = *d; wa.Z = fa.Z; wa.D = fa.D; wa.npad = fa.npad; wa.nsplit = nsplit; wa.slabs = ws + wl.slabs;
         wa.stamps = ws + wl.rec + (int64_t)kCUs * kRecWgsPerCu * 4 * BRIEF_REC_FLOATS - 256 * 8 * 8;   // tail of the record region (diagnostics)
         const int blocks = nsplit * (d->layers - 2) * wgrad_nq(nt) * wgrad_nq(nt);
+        if (d->precision == BRIEF_PREC_BF16X3) {
+            hipLaunchKernelGGL(k_wgrad_x3, dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(8), st, wa);
+        } else
 #define BRIEF_CASE(NTV)                                                                                    \
     case NTV:                                                                                              \
         hipLaunchKernelGGL((k_wgrad<NTV>), dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(NTV), st, wa); \

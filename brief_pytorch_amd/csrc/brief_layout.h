@@ -52,6 +52,7 @@ BL_HD int brief_nt(const brief_siren_desc &d)
 {
     const int nt = (d.features + 31) / 32;
     if (d.precision == BRIEF_PREC_BF16) return nt <= 8 ? 8 : 16;     // the bf16 kernels exist for 256 and 512 padded features
+    if (d.precision == BRIEF_PREC_BF16X3) return 8;                  // split precision: one kernel set, 256 padded features (check_desc: F <= 256)
     return nt <= 8 ? nt : (nt <= 12 ? 12 : 16);
 }
 BL_HD int64_t brief_pk_w0(const brief_siren_desc &) { return 0; }
@@ -86,10 +87,18 @@ BL_HD int64_t brief_pk16_off(const brief_siren_desc &d, int l /*1..L-2*/)
     const int64_t FP = 32 * brief_nt(d);
     return ((brief_pk_count32(d) + 3) / 4) * 4 + (int64_t)(l - 1) * FP * FP;
 }
+// BRIEF_PREC_BF16X3 keeps the whole f32 buffer (the decode kernels read it) and appends TWO bf16 regions of the bf16 mode's
+// shape: the hi halves bf16(w) and, (L-2) FP^2 floats further, the lo halves bf16(w - hi) of the same (scaled) weights
+BL_HD int64_t brief_pk16_region(const brief_siren_desc &d)
+{
+    const int64_t FP = 32 * brief_nt(d), hidden = d.layers - 2 > 0 ? d.layers - 2 : 0;
+    return hidden * FP * FP;
+}
 BL_HD int64_t brief_pk_count(const brief_siren_desc &d)
 {
-    if (d.precision != BRIEF_PREC_BF16) return brief_pk_count32(d);
-    return brief_pk16_off(d, d.layers - 1 > 1 ? d.layers - 1 : 1);
+    if (d.precision == BRIEF_PREC_BF16) return brief_pk16_off(d, 1) + brief_pk16_region(d);
+    if (d.precision == BRIEF_PREC_BF16X3) return brief_pk16_off(d, 1) + 2 * brief_pk16_region(d);
+    return brief_pk_count32(d);
 }
 // index (in bf16 elements, inside one layer's Wf16 or Wb16 block) of the fragment element that multiplies
 // activation row `col` into output row `row`

@@ -40,9 +40,13 @@ typedef struct {
     int32_t precision;   /* BRIEF_PREC_F32 (0): exact f32 MFMA everywhere.  BRIEF_PREC_BF16 (1): the hidden F x F GEMMs run on the
                           * bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, f32 accumulate, f32 master weights, f32 first layer, head,
                           * loss, reductions and optimizer); activations/deltas are stashed as bf16.  The MI355X counterpart of the
-                          * reference's low-precision mode (Compress.half, main.py:388-399), pinned by a PSNR band, not bitwise. */
+                          * reference's low-precision mode (Compress.half, main.py:388-399), pinned by a PSNR band, not bitwise.
+                          * BRIEF_PREC_BF16X3 (2), features <= 256: split precision — weights, activations and deltas of the hidden GEMMs
+                          * are split into hi + lo bf16 halves and every product is three bf16 MFMAs (hi.hi + hi.lo + lo.hi, f32
+                          * accumulate): ~16 significant bits per operand, held to the SAME oracle bands as BRIEF_PREC_F32 (forward 2e-5,
+                          * gradients 1e-4, traces 1e-4) but not bit-identical to it; never the default.  Decode runs the f32 kernels. */
 } brief_siren_desc;
-enum { BRIEF_PREC_F32 = 0, BRIEF_PREC_BF16 = 1 };
+enum { BRIEF_PREC_F32 = 0, BRIEF_PREC_BF16 = 1, BRIEF_PREC_BF16X3 = 2 };
 
 /* create_flattened_coords(shape, mode)  utils/dataset.py:36-60: linspace(lo,hi,n) per axis, (d,h,w) order */
 typedef struct {
