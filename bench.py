@@ -42,6 +42,18 @@ from brief_pytorch_amd.synthetic import make_volume_torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz x 256 FLOP/clk
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # same guide: dense bf16 (v_mfma_f32_32x32x16_bf16); only used by --precision bf16
+# --precision bf16x3 (BRIEF_PREC_BF16X3): every product is three bf16 MFMAs (hi*hi + hi*lo + lo*hi), so the algorithmic flops
+# (counted once, as for f32) are priced against a third of the bf16 peak
+PEAKS = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "bf16x3": PEAK_BF16_MFMA_TFLOPS / 3.0}
+DTYPES = {"fp32": "f32", "bf16": "bf16", "bf16x3": "bf16x3"}
+
+
+def fused_kernel_name(precision, F):
+    if precision == "fp32":
+        return "k_fused<%d,true>" % (F // 32)
+    if precision == "bf16x3":
+        return "k_fused<8,true,2> (split-precision bf16 MFMA, 3 per product)"
+    return "k16<%d,true,1>" % (F // 32)
 LAYERS, FEATURES, W0, SAMPLE = 5, 256, 20.0, 100000      # BASELINE config 2 (the metric's shape); --config c3 = 8x512
 BLOCK = (512, 512, 512)
 
@@ -238,15 +250,15 @@ def timed_config(name, L, F, dims, sampler, n, precision, steps, tgt=None, seed=
     _lib.check(L_.brief_profile_fused(C.byref(tot_ms), C.byref(launches)))
     _lib.check(L_.brief_profile_enable(0))
     train_f, fused_f, _ = flops_per_sample(L, F)
-    peak = PEAK_F32_MFMA_TFLOPS if precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
+    peak = PEAKS[precision]
     nb = fit.n
     kms = tot_ms.value / max(launches.value, 1)
     small = F <= 64 and precision == "fp32"              # k_small is the whole train step but the reduction
     kflop = (train_f if small else fused_f) * nb
-    return {"workload": name, "layers": L, "features": F, "volume": list(dims), "samples_per_step": nb, "dtype": "f32" if precision == "fp32" else "bf16",
+    return {"workload": name, "layers": L, "features": F, "volume": list(dims), "samples_per_step": nb, "dtype": DTYPES[precision],
             "steps": steps, "ms_per_step": el * 1e3 / steps, "voxels_per_s": nb * steps / el,
             "step_tflops": train_f * nb / (el / steps) / 1e12, "step_frac": train_f * nb / (el / steps) / 1e12 / peak,
-            "kernel": "k_small" if small else ("k_fused" if precision == "fp32" else "k16 (body + tail launches)"),
+            "kernel": "k_small" if small else {"fp32": "k_fused", "bf16x3": "k_fused<8,true,2>", "bf16": "k16 (body + tail launches)"}[precision],
             "kernel_ms": kms, "kernel_tflops": kflop / (kms * 1e-3) / 1e12, "kernel_frac": kflop / (kms * 1e-3) / 1e12 / peak, "peak_tflops": peak}
 
 
@@ -321,8 +333,9 @@ def main():
     ap.add_argument("--encode-steps", type=int, default=2000, help="total optimizer steps of the end-to-end encode figure / psnr_at_bitrate (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-psnr", action="store_true")
-    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
-                    help="fp32 = the metric (exact f32 MFMA); bf16 = BASELINE config 3's arithmetic (extra lines, never the default)")
+    ap.add_argument("--precision", choices=["fp32", "bf16", "bf16x3"], default="fp32",
+                    help="fp32 = the metric (exact f32 MFMA); bf16 = BASELINE config 3's arithmetic; bf16x3 = split-precision bf16 MFMAs that "
+                         "meet the fp32 parity bands (extra lines, never the default)")
     ap.add_argument("--config", choices=["c2", "c3"], default="c2", help="c2: 4x256 SIREN (the metric); c3: 8x512 SIREN")
     ap.add_argument("--divide", action="store_true", help="run the DivideTask product path also at world size 1 (one block, process group initialised)")
     ap.add_argument("--block", type=int, default=512, help="edge of the cubic block (tests only; the metric is quoted on 512)")
@@ -375,19 +388,19 @@ def main():
         elapsed, fused_ms, perf, pcount = divide_bench(args, dist, rank, world, dev, red_dev)
         if rank == 0:
             train_f, fused_f, _ = flops_per_sample(LAYERS, FEATURES)
-            peak = PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
+            peak = PEAKS[args.precision]
             ms_step = elapsed * 1e3 / args.steps
             achieved = fused_f * SAMPLE / (fused_ms * 1e-3) / 1e12
             out = {
                 "metric": "encode_voxels_per_sec", "value": SAMPLE * args.steps * world / elapsed, "unit": "voxels/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
+                "vs_baseline": None, "dtype": DTYPES[args.precision], "data": "synthetic",
                 "config": {"workload": "DivideTask (NFGR.compress_divide) on a synthetic uint16 volume of %d x %d^3 blocks (total_%d_1_1), one block and "
                                        "one SIREN %dx%d (layers=%d, features=%d, w0=20) per rank, randompoint sample_size=100000, datal2, Adamax lr=1e-3"
                                        % (world, BLOCK[0], world, LAYERS - 1, FEATURES, LAYERS, FEATURES),
                            "volume": [world * BLOCK[0], BLOCK[1], BLOCK[2]], "layers": LAYERS, "features": FEATURES, "sample_size": SAMPLE,
                            "params": pcount, "bits_per_voxel": 32.0 * pcount / float(np.prod(BLOCK))},
-                "roofline": {"bound": "mfma", "kernel": ("k_fused<%d,true>" if args.precision == "fp32" else "k16<%d,true,1>") % (FEATURES // 32)
+                "roofline": {"bound": "mfma", "kernel": fused_kernel_name(args.precision, FEATURES)
                              + " (forward+loss+dgrad), rank 0", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                              "traffic": None, "traffic_source": None, "kernel_ms": fused_ms, "flop_per_launch": fused_f * SAMPLE,
                              "step_tflops": train_f * SAMPLE / (ms_step * 1e-3) / 1e12, "step_frac": train_f * SAMPLE / (ms_step * 1e-3) / 1e12 / peak},
@@ -482,6 +495,10 @@ def main():
                                                             "full-volume batch", 5, 22, (64, 64, 64), "full", 0, "fp32", 400)
             cfgs["c3_512cube_8x512_bf16"] = timed_config("SingleTask 512^3 synthetic volume, SIREN 8x512 (layers=9, features=512), bf16 MFMA with f32 master weights, "
                                                          "randompoint sample_size=100000", 9, 512, BLOCK, "randompoint", SAMPLE, "bf16", 60, tgt=tgt)
+            cfgs["c2_512cube_4x256_bf16x3"] = timed_config("the headline workload (SingleTask 512^3, SIREN 4x256, randompoint sample_size=100000) under precision="
+                                                           "bf16x3: hidden GEMMs as three bf16 MFMAs per product on hi/lo operand halves, f32 accumulate and stashes; "
+                                                           "passes the fp32 parity bands (tests/test_gpu_bf16x3.py); priced against bf16 peak / 3; not the metric",
+                                                           LAYERS, FEATURES, BLOCK, "randompoint", SAMPLE, "bf16x3", 200, tgt=tgt)
             extra["configs"] = cfgs
             # ---- PSNR against bitrate on the 512^3 volume: three net sizes, --encode-steps steps each
             pts = [rate_point(128, tgt, vol, vmin, vmax, steps_done),
@@ -506,7 +523,7 @@ def main():
             except Exception:
                 pass
         train_f, fused_f, _ = flops_per_sample(LAYERS, FEATURES)
-        peak = PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
+        peak = PEAKS[args.precision]
         if args.precision != "fp32" or args.config != "c2":
             traffic, traffic_src = None, None       # the committed counter passes are for the default configuration only
         fused_ms = tot_ms.value / max(launches.value, 1)
@@ -516,14 +533,14 @@ def main():
         out = {
             "metric": "encode_voxels_per_sec", "value": value, "unit": "voxels/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": DTYPES[args.precision], "data": "synthetic",
             "config": {"workload": "SingleTask 512^3 synthetic uint16 volume%s, SIREN %dx%d (layers=%d, features=%d, w0=20), "
                                    "randompoint sample_size=100000, datal2, Adamax lr=1e-3" %
                                    ("" if world == 1 else " per rank (DivideTask: %d independent 512^3 blocks)" % world,
                                     LAYERS - 1, FEATURES, LAYERS, FEATURES),
                        "volume": list(BLOCK), "layers": LAYERS, "features": FEATURES, "sample_size": SAMPLE,
                        "params": net.param_count, "bits_per_voxel": 32.0 * net.param_count / float(np.prod(BLOCK))},
-            "roofline": {"bound": "mfma", "kernel": ("k_fused<%d,true>" if args.precision == "fp32" else "k16<%d,true,1>") % (FEATURES // 32)
+            "roofline": {"bound": "mfma", "kernel": fused_kernel_name(args.precision, FEATURES)
                          + " (forward+loss+dgrad)", "achieved": achieved,
                          "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": fused_ms, "flop_per_launch": fused_f * SAMPLE,

@@ -309,7 +309,10 @@ __device__ __forceinline__ void x3_chain(f32x16 (&acc)[KCfg<NT>::MTW], __amdgpu_
 {
     using K = KCfg<NT>;
     constexpr int NIT = NT * 2;
-    constexpr int PD = 2;
+#ifndef BRIEF_X3_PD
+#define BRIEF_X3_PD 6
+#endif
+    constexpr int PD = BRIEF_X3_PD;      // k-steps of A fragments (hi + lo: 4 KB per step and wave) in flight
     const int voff = lane * 16;
     int soff_w = soff_layer + wm * (NT * 2 * 1024);
     asm volatile("" : "+s"(soff_w));
@@ -581,7 +584,7 @@ __global__ __launch_bounds__(256, TRAIN ? (PREC == 2 ? 2 : fused_train_wpe(NT)) 
         for (int l = 0; l <= L - 2; ++l) {
             const bool last = (l == L - 2);
             if (l > 0) {
-                if (TRAIN && fused_lean(NT)) FUSED_LOAD_BIAS(l)      // lean variant: no register set parked across the epilogue
+                if (TRAIN && fused_lean(NT) && PREC != 2) FUSED_LOAD_BIAS(l)      // lean variant: no register set parked across the epilogue
 #pragma unroll
                 for (int t = 0; t < K::MTW; ++t) {
 #pragma unroll
@@ -600,7 +603,7 @@ __global__ __launch_bounds__(256, TRAIN ? (PREC == 2 ? 2 : fused_train_wpe(NT)) 
                 lds_barrier();   // every wave is done reading the previous image
                 STAMP(2)
             }
-            if (!last && !(TRAIN && fused_lean(NT))) FUSED_LOAD_BIAS(l + 1)   // lands while this epilogue computes its sines
+            if (!last && !(TRAIN && fused_lean(NT) && PREC != 2)) FUSED_LOAD_BIAS(l + 1)   // lands while this epilogue computes its sines
             // epilogue: stash z, h = sin(om z) (+ c = om cos(om z) on the last sine layer)
 #pragma unroll
             for (int t = 0; t < K::MTW; ++t) {
@@ -835,7 +838,7 @@ __global__ __launch_bounds__(256, TRAIN ? (PREC == 2 ? 2 : fused_train_wpe(NT)) 
             const __amdgpu_buffer_rsrc_t rzp =
                 __builtin_amdgcn_make_buffer_rsrc((void *)(a.Z + (int64_t)(l - 1) * K::FP * npad), 0, stash_bytes, 0x00020000);
             float zr[K::MTW][16];
-            constexpr bool ZPRE = !fused_lean(NT);      // lean variant: the phases are fetched after the chain (two other waves cover the latency)
+            constexpr bool ZPRE = !(fused_lean(NT) && PREC != 2);      // (the split-precision kernel runs two workgroups per CU and keeps its prefetches)      // lean variant: the phases are fetched after the chain (two other waves cover the latency)
 #define FUSED_LOAD_Z()                                                                                  \
     _Pragma("unroll") for (int t = 0; t < K::MTW; ++t) {                                                \
         const int mt = wm + K::WM * t;                                                                  \

@@ -1,0 +1,136 @@
+"""BRIEF_PREC_BF16X3 (`precision="bf16x3"`): split-precision hidden GEMMs — every operand hi + lo bf16, three bf16 MFMAs per
+product — held to the SAME bands as the fp32 path (forward 2e-5 of max|y|, loss 1e-5, every gradient tensor 1e-4 of its max-abs,
+loss traces 1e-4 against the reference's goldens / the oracle), which the bf16 mode (bands 1e-2) is not.  Never the default and not
+bit-identical to fp32; the decode kernels are the fp32 ones (bit-identical output)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from brief_pytorch_amd import _lib
+from brief_pytorch_amd.fit import Fitter, MultiFitter
+from brief_pytorch_amd.networks import SIREN
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-30))
+
+
+def _net(L, F, w0=20.0, cin=3, cout=1, seed=0, precision="bf16x3", ws=None, bs=None):
+    torch.manual_seed(seed)
+    m = SIREN(coords_channel=cin, data_channel=cout, features=F, layers=L, w0=w0, precision=precision)
+    if ws is not None:
+        for l in range(L):
+            m.net[l][0].weight.data = torch.from_numpy(ws[l])
+            m.net[l][0].bias.data = torch.from_numpy(bs[l])
+    p = m.params.numpy().copy()
+    return m.to(DEV), O.make_desc(cin, cout, L, F, w0), p
+
+
+@pytest.mark.parametrize("L,F,cin,cout,n,use_w,loss", [(5, 256, 3, 1, 20000, False, "datal2"), (4, 128, 3, 1, 5000, True, "datal2"),
+                                                      (3, 200, 2, 3, 3333, False, "datasmoothl1"), (6, 96, 3, 1, 1000, True, "datal2"),
+                                                      (9, 160, 3, 2, 2049, False, "datal2"), (2, 70, 3, 1, 31, False, "datal2"),
+                                                      (5, 33, 3, 1, 700, True, "datasmoothl1")])
+def test_train_step_meets_the_fp32_bands(L, F, cin, cout, n, use_w, loss):
+    m, d, p = _net(L, F, cin=cin, cout=cout, seed=L * 100 + F)
+    rng = np.random.default_rng(F + n)
+    x = rng.uniform(-1, 1, size=(n, cin)).astype(np.float32)
+    y = rng.uniform(0, 100, size=(n, cout)).astype(np.float32)
+    w = np.where(rng.uniform(size=(n, cout)) < 0.5, 0.25, 1.0).astype(np.float32) if use_w else None
+    kind, beta, thr = (1, 0.5, 30.0) if loss == "datasmoothl1" else (0, 0.01, 0.0)
+    l1, yh = m.train_step(n, torch.from_numpy(y).to(DEV), coords=torch.from_numpy(x).to(DEV), weights=torch.from_numpy(w).to(DEV) if use_w else None,
+                          loss=loss, thr=thr, beta=beta, want_yhat=True)
+    g1 = m.grads.clone()
+    lo, go, yo, _ = O.loss_grad(d, p, x, y, w, kind, thr, beta)
+    assert relerr(yh.cpu().numpy(), yo) < 2e-5
+    assert abs(l1.item() - lo) / abs(lo) < 1e-5
+    gw, gb = O.unpack_params(d, go)
+    mw, mb = O.unpack_params(d, m.grads.cpu().numpy())
+    worst = max(max(relerr(mw[k], gw[k]), relerr(mb[k], gb[k])) for k in range(L))
+    assert worst < 1e-4, worst
+    l2, _ = m.train_step(n, torch.from_numpy(y).to(DEV), coords=torch.from_numpy(x).to(DEV), weights=torch.from_numpy(w).to(DEV) if use_w else None,
+                         loss=loss, thr=thr, beta=beta)
+    assert torch.equal(g1, m.grads) and l1.item() == l2.item()          # fixed summation order: bit-reproducible
+
+
+def test_forward_and_decode_are_the_fp32_kernels():
+    a, _, _ = _net(5, 200, seed=3, precision="bf16x3")
+    b, _, _ = _net(5, 200, seed=3, precision="fp32")
+    x = torch.from_numpy(np.random.default_rng(1).uniform(-1, 1, size=(777, 3)).astype(np.float32)).to(DEV)
+    assert torch.equal(a.forward(x), b.forward(x))
+    assert torch.equal(a.decode_grid((9, 10, 11)), b.decode_grid((9, 10, 11)))
+
+
+def test_trace_against_the_reference_golden_and_fit_loop_identities(golden):
+    """the 3000-step golden's net (5x128, full batch of 30 720 samples) for its first 50 steps against the REFERENCE's own loss
+    trace at the fp32 band (1e-4), through brief_siren_fit; run(k) == k x step() and co-trained == alone, bit for bit"""
+    g = golden("half")
+    L, F, w0, _ = (int(v) for v in g["cfg"])
+    vol = g["vol"]
+    vn, side = O.normalize(vol)
+    thr = float(O.normalize(np.array([65535], np.uint16), vmin=side["min"], vmax=side["max"])[0][0])
+    tv = torch.from_numpy(vn.reshape(-1, 1)).to(DEV)
+    fits = []
+    for _ in range(3):
+        m, _, _ = _net(L, F, w0=float(w0), ws=[g["init_w%d" % l] for l in range(L)], bs=[g["init_b%d" % l] for l in range(L)])
+        fits.append(Fitter(m, tv, vol.shape[:3], sampler="full", optimizer="Adamax", lr=1e-3, thr=thr,
+                           scheduler={"name": "MultiStepLR", "milestones": [50000, 60000, 70000], "gamma": 0.2}))
+    trace = fits[0].run(50, log=True).cpu().numpy().astype(np.float64)
+    ref = g["f32_losses"][:50]
+    err = np.abs(trace - ref) / ref
+    print("bf16x3 50-step trace against the reference's run: max relative error %.2e" % err.max())
+    assert err.max() < 1e-4
+    stepped = np.asarray([float(fits[1].step()) for _ in range(50)], np.float32)
+    assert np.array_equal(stepped, trace.astype(np.float32)) and torch.equal(fits[0].m.params, fits[1].m.params) and torch.equal(fits[0].m.packed, fits[1].m.packed)
+    other, _, _ = _net(4, 22, seed=8, precision="fp32")
+    tv2 = (torch.rand(16 ** 3, 1, generator=torch.Generator().manual_seed(2)) * 100).to(DEV)
+    solo = Fitter(other, tv2, (16, 16, 16), sampler="full")
+    solo2, _, _ = _net(4, 22, seed=8, precision="fp32")
+    grp = MultiFitter([fits[2], Fitter(solo2, tv2, (16, 16, 16), sampler="full")])
+    grp.run(50)
+    solo.run(50)
+    assert torch.equal(fits[2].m.params, fits[0].m.params) and torch.equal(solo2.params, other.params)
+
+
+def test_full_size_step_and_trace_of_the_headline_shape():
+    """BASELINE config 2's shape (4x256, 100 000 randompoint samples of a 256^3 volume): one step against the oracle at the
+    fp32 bands, then 12 optimizer steps against the oracle's loop (trace 1e-4)"""
+    from brief_pytorch_amd.synthetic import make_volume_torch
+    dims, L, F, N = (256, 256, 256), 5, 256, 100000
+    vol = make_volume_torch(dims, seed=11, device=DEV)
+    t = vol.view(-1, 1).to(torch.float32)
+    tgt = (t - t.min()) / (t.max() - t.min()) * 100.0
+    m, d, p0 = _net(L, F, seed=12)
+    pop = tgt.shape[0]
+    idx = torch.empty(N, dtype=torch.int64, device=DEV)
+    _lib.check(_lib.lib().brief_sample_indices(_lib.ptr(idx), N, pop, 77, 1, _lib.stream_ptr()))
+    loss, yh = m.train_step(N, tgt, idx=idx, grid=(dims, -1.0, 1.0), want_yhat=True)
+    ih = idx.cpu().numpy()
+    tgt_h = tgt.cpu().numpy()
+    lo, go, yo, _ = O.loss_grad(d, p0, O.grid_coords(dims, idx=ih), tgt_h[ih])
+    gw, gb = O.unpack_params(d, go)
+    mw, mb = O.unpack_params(d, m.grads.cpu().numpy())
+    worst = max(max(relerr(mw[k], gw[k]), relerr(mb[k], gb[k])) for k in range(L))
+    print("bf16x3 full-size step: yhat %.2e loss %.2e worst gradient tensor %.2e" % (relerr(yh.cpu().numpy(), yo), abs(loss.item() - lo) / lo, worst))
+    assert relerr(yh.cpu().numpy(), yo) < 2e-5 and abs(loss.item() - lo) / lo < 1e-5 and worst < 1e-4
+    steps = 12
+    fit = Fitter(m, tgt, dims, sampler="randompoint", sample_size=N, optimizer="Adamax", lr=1e-3, seed=77)
+    trace = fit.run(steps, log=True).cpu().numpy().astype(np.float64)
+    p, s1, s2 = p0.copy(), np.zeros_like(p0), np.zeros_like(p0)
+    ref = []
+    for k in range(1, steps + 1):
+        _lib.check(_lib.lib().brief_sample_indices(_lib.ptr(idx), N, pop, 77, k, _lib.stream_ptr()))
+        ih = idx.cpu().numpy()
+        l_k, g_k, _, _ = O.loss_grad(d, p, O.grid_coords(dims, idx=ih), tgt_h[ih])
+        O.optim_step("Adamax", p, g_k, s1, s2, 1e-3, k)
+        ref.append(l_k)
+    err = np.abs(trace - np.asarray(ref)) / np.asarray(ref)
+    print("bf16x3 full-size trace over %d steps: max relative error %.2e" % (steps, err.max()))
+    assert err.max() < 1e-4
+

@@ -114,3 +114,17 @@ def test_bf16_packed_layout_counts():
     assert 2 * plane < L.brief_train_workspace_bytes(C.byref(d), 100000) < 2.2 * plane      # the fp16 phase planes + the bf16 delta planes (round 3: no cosine planes)
     bad = _lib.SirenDesc(3, 1, 5, 256, 20.0, 30.0, 0, 7)
     assert L.brief_packed_count(C.byref(bad)) < 0 and b"precision" in L.brief_last_error()
+
+
+def test_bf16x3_packed_layout_counts_and_limits():
+    """BRIEF_PREC_BF16X3: every net runs on the 256-wide tile; the packed buffer is the f32 buffer + one hi and one lo bf16
+    fragment region (W and W^T of each hidden layer: FP^2 dwords per layer and half); widths above 256 are refused"""
+    import ctypes as C
+    L = _lib.lib()
+    assert _lib.PRECISION["bf16x3"] == 2
+    c32 = 256 * 4 + 3 * (2 * 256 * 256 + 256) + 4 * 256 + 4
+    for F in (256, 200, 22):
+        d = _lib.SirenDesc(3, 1, 5, F, 20.0, 30.0, 0, 2)
+        assert L.brief_packed_count(C.byref(d)) == (c32 + 3) // 4 * 4 + 2 * 3 * 256 * 256
+    wide = _lib.SirenDesc(3, 1, 5, 300, 20.0, 30.0, 0, 2)
+    assert L.brief_packed_count(C.byref(wide)) < 0 and b"256" in L.brief_last_error()
