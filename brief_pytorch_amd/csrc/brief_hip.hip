@@ -310,7 +310,7 @@ __device__ __forceinline__ void x3_chain(f32x16 (&acc)[KCfg<NT>::MTW], __amdgpu_
     using K = KCfg<NT>;
     constexpr int NIT = NT * 2;
 #ifndef BRIEF_X3_PD
-#define BRIEF_X3_PD 6
+#define BRIEF_X3_PD 4
 #endif
     constexpr int PD = BRIEF_X3_PD;      // k-steps of A fragments (hi + lo: 4 KB per step and wave) in flight
     const int voff = lane * 16;
@@ -329,16 +329,18 @@ __device__ __forceinline__ void x3_chain(f32x16 (&acc)[KCfg<NT>::MTW], __amdgpu_
             alo[it_][t] = make_uint4(vl.x, vl.y, vl.z, vl.w);                                                \
         }                                                                                                    \
     }
+    // The loads are NOT predicated on kit (the padded k-steps hold zero fragments and zero activations): behind a wave-uniform
+    // branch the compiler's s_waitcnt bookkeeping joins the two paths pessimistically and waits for vmcnt(0) — the fragments
+    // fetched PD steps ahead included — inside every k-step, which is a prefetch depth of one.  Only the MFMAs are skipped.
 #pragma unroll
-    for (int it = 0; it < PD; ++it)
-        if (it < kit) X3_LOAD(it)
+    for (int it = 0; it < PD; ++it) X3_LOAD(it)
     bhi[0] = X16[lane]; blo[0] = X16[NT * 2 * 64 + lane];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        // (no early exit: a runtime `break` keeps hipcc from unrolling, and the fragment arrays then live in scratch; the steps
-        //  above kit — zero weight columns against zero activations — are skipped by wave-uniform branches instead)
-        if (it + PD < NIT && it + PD < kit) X3_LOAD(it + PD)
-        if (it + 1 < NIT && it + 1 < kit) { bhi[it + 1] = X16[(it + 1) * 64 + lane]; blo[it + 1] = X16[NT * 2 * 64 + (it + 1) * 64 + lane]; }
+#ifndef BRIEF_X3_NOLOAD      // diagnostic build: only the first PD k-steps of weight fragments are fetched (results are garbage)
+        if (it + PD < NIT) X3_LOAD(it + PD)
+#endif
+        if (it + 1 < NIT) { bhi[it + 1] = X16[(it + 1) * 64 + lane]; blo[it + 1] = X16[NT * 2 * 64 + (it + 1) * 64 + lane]; }
         __builtin_amdgcn_sched_barrier(0);
         if (it < kit) {
             X3Frag fbh, fbl;
@@ -347,7 +349,11 @@ __device__ __forceinline__ void x3_chain(f32x16 (&acc)[KCfg<NT>::MTW], __amdgpu_
             for (int t = 0; t < K::MTW; ++t) {
                 if (K::EXACT || wm + K::WM * t < NT) {
                     X3Frag fah, fal;
+#ifdef BRIEF_X3_NOLOAD
+                    fah.u = ahi[it % PD][t]; fal.u = alo[it % PD][t];
+#else
                     fah.u = ahi[it][t]; fal.u = alo[it][t];
+#endif
                     acc[t] = MFMA_X3(fah.v, fbh.v, acc[t]);
                     acc[t] = MFMA_X3(fah.v, fbl.v, acc[t]);
                     acc[t] = MFMA_X3(fal.v, fbh.v, acc[t]);
@@ -416,9 +422,16 @@ struct FusedLds {
 #define BRIEF_LEAN 1
 #endif
 constexpr bool fused_lean(int NT) { return BRIEF_LEAN && NT == 8; }
+#ifndef BRIEF_X3_LEAN
+#define BRIEF_X3_LEAN 0      // the split-precision kernel (two workgroups per CU) keeps its bias / phase prefetches
+#endif
+#ifndef BRIEF_X3_WPE
+#define BRIEF_X3_WPE 2
+#endif
+constexpr bool fused_lean_p(int NT, int PREC) { return PREC == 2 ? (bool)BRIEF_X3_LEAN : fused_lean(NT); }
 constexpr int fused_train_wpe(int NT) { return NT > 8 ? 1 : (NT <= 4 || fused_lean(NT) ? (BRIEF_TRAIN_WPE > 3 ? BRIEF_TRAIN_WPE : 3) : BRIEF_TRAIN_WPE); }
 template <int NT, bool TRAIN, int PREC = 0 /* 0: f32 MFMA; 2: BRIEF_PREC_BF16X3 hidden GEMMs (x3_chain) */>
-__global__ __launch_bounds__(256, TRAIN ? (PREC == 2 ? 2 : fused_train_wpe(NT)) : (NT > 8 ? 2 : 3)) void k_fused(const FusedArgs a)
+__global__ __launch_bounds__(256, TRAIN ? (PREC == 2 ? BRIEF_X3_WPE : fused_train_wpe(NT)) : (NT > 8 ? 2 : 3)) void k_fused(const FusedArgs a)
 {
 #ifdef BRIEF_STAMPS
     float st_acc[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -456,7 +469,6 @@ __global__ __launch_bounds__(256, TRAIN ? (PREC == 2 ? 2 : fused_train_wpe(NT)) 
     const __amdgpu_buffer_rsrc_t rs_pk =
         __builtin_amdgcn_make_buffer_rsrc((void *)pk, 0, (int)(brief_pk_count(d) * 4), 0x00020000);
     const int stash_bytes = (a.diag & 1) ? 0 : (int)((int64_t)K::FP * npad * 4);   // one [FP][npad] panel (host checks < 2^31)
-    const int row_bytes = (int)(npad * 4);
 
     // head weights -> LDS once per workgroup (every lane needs all of them in the head dot product)
     {
@@ -584,7 +596,7 @@ __global__ __launch_bounds__(256, TRAIN ? (PREC == 2 ? 2 : fused_train_wpe(NT)) 
         for (int l = 0; l <= L - 2; ++l) {
             const bool last = (l == L - 2);
             if (l > 0) {
-                if (TRAIN && fused_lean(NT) && PREC != 2) FUSED_LOAD_BIAS(l)      // lean variant: no register set parked across the epilogue
+                if (TRAIN && fused_lean_p(NT, PREC)) FUSED_LOAD_BIAS(l)      // lean variant: no register set parked across the epilogue
 #pragma unroll
                 for (int t = 0; t < K::MTW; ++t) {
 #pragma unroll
@@ -603,7 +615,7 @@ __global__ __launch_bounds__(256, TRAIN ? (PREC == 2 ? 2 : fused_train_wpe(NT)) 
                 lds_barrier();   // every wave is done reading the previous image
                 STAMP(2)
             }
-            if (!last && !(TRAIN && fused_lean(NT) && PREC != 2)) FUSED_LOAD_BIAS(l + 1)   // lands while this epilogue computes its sines
+            if (!last && !(TRAIN && fused_lean_p(NT, PREC))) FUSED_LOAD_BIAS(l + 1)   // lands while this epilogue computes its sines
             // epilogue: stash z, h = sin(om z) (+ c = om cos(om z) on the last sine layer)
 #pragma unroll
             for (int t = 0; t < K::MTW; ++t) {
@@ -617,12 +629,12 @@ __global__ __launch_bounds__(256, TRAIN ? (PREC == 2 ? 2 : fused_train_wpe(NT)) 
                     if (TRAIN && !last) {
                         const __amdgpu_buffer_rsrc_t rz =
                             __builtin_amdgcn_make_buffer_rsrc((void *)(a.Z + (int64_t)l * K::FP * npad), 0, stash_bytes, 0x00020000);
-                        int rbz = row_bytes;
-                        asm volatile("" : "+s"(rbz));      // keep the 16 row offsets in-loop scalar math
-                        const int voff = (int)(n * 4) + hi * 4 * rbz;
+                        // stash planes are tile-blocked, [32-sample tile][FP rows][32 samples]: a tile's block is one contiguous
+                        // 4 * 32 * FP bytes (rows 128 B apart), for this kernel's stores and reloads and for k_wgrad's panels
+                        const int voff = (int)(n0 * (K::FP * 4)) + ln * 4 + hi * 4 * 128;
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
-                            bstore1(acc[t][r], rz, voff, (32 * mt + (r & 3) + 8 * (r >> 2)) * rbz);
+                            bstore1(acc[t][r], rz, voff, (32 * mt + (r & 3) + 8 * (r >> 2)) * 128);
                     }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) hreg[t][r] = BRIEF_SIN_REV(acc[t][r]);
@@ -822,29 +834,27 @@ __global__ __launch_bounds__(256, TRAIN ? (PREC == 2 ? 2 : fused_train_wpe(NT)) 
             // stash delta_l for the weight-gradient GEMM and publish it as the B image
             const __amdgpu_buffer_rsrc_t rd =
                 __builtin_amdgcn_make_buffer_rsrc((void *)(a.D + (int64_t)(l - 1) * K::FP * npad), 0, stash_bytes, 0x00020000);
-            int rbd = row_bytes;
-            asm volatile("" : "+s"(rbd));
-            const int voff_s = (int)(n * 4) + hi * 4 * rbd;
+            const int voff_s = (int)(n0 * (K::FP * 4)) + ln * 4 + hi * 4 * 128;
 #pragma unroll
             for (int t = 0; t < K::MTW; ++t) {
                 const int mt = wm + K::WM * t;
                 if (K::EXACT || mt < NT) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        bstore1(dl[t][r], rd, voff_s, (32 * mt + (r & 3) + 8 * (r >> 2)) * rbd);
+                        bstore1(dl[t][r], rd, voff_s, (32 * mt + (r & 3) + 8 * (r >> 2)) * 128);
                 }
             }
             // z_{l-1} comes back from the stash while the chain runs (it is only needed after it)
             const __amdgpu_buffer_rsrc_t rzp =
                 __builtin_amdgcn_make_buffer_rsrc((void *)(a.Z + (int64_t)(l - 1) * K::FP * npad), 0, stash_bytes, 0x00020000);
             float zr[K::MTW][16];
-            constexpr bool ZPRE = !(fused_lean(NT) && PREC != 2);      // (the split-precision kernel runs two workgroups per CU and keeps its prefetches)      // lean variant: the phases are fetched after the chain (two other waves cover the latency)
+            constexpr bool ZPRE = !fused_lean_p(NT, PREC);      // lean variant: the phases are fetched after the chain (two other waves cover the latency)
 #define FUSED_LOAD_Z()                                                                                  \
     _Pragma("unroll") for (int t = 0; t < K::MTW; ++t) {                                                \
         const int mt = wm + K::WM * t;                                                                  \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                \
             zr[t][r] = 0.f;                                                                             \
-            if (K::EXACT || mt < NT) zr[t][r] = bload1(rzp, voff_s, (32 * mt + (r & 3) + 8 * (r >> 2)) * rbd); \
+            if (K::EXACT || mt < NT) zr[t][r] = bload1(rzp, voff_s, (32 * mt + (r & 3) + 8 * (r >> 2)) * 128); \
         }                                                                                               \
     }
             if (ZPRE) FUSED_LOAD_Z()
@@ -1419,8 +1429,9 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
     const int split = bsl % a.nsplit;
     const int64_t nchunks = a.npad / 32;
     const int64_t c0 = nchunks * split / a.nsplit, c1 = nchunks * (split + 1) / a.nsplit;   // c1 > c0 (host: nsplit <= nchunks)
-    const float *Dl = a.D + ((int64_t)(l - 1) * FP + qm * QP) * a.npad;     // this quadrant's delta rows
-    const float *Zl = a.Z + ((int64_t)(l - 1) * FP + qn * QP) * a.npad;     // ... and z rows
+    // stash planes are [32-sample chunk][FP rows][32 samples]: this quadrant's rows of a chunk are QP * 128 contiguous bytes
+    const float *Dl = a.D + (int64_t)(l - 1) * FP * a.npad + qm * QP * 32;     // this quadrant's delta rows (of chunk 0)
+    const float *Zl = a.Z + (int64_t)(l - 1) * FP * a.npad + qn * QP * 32;     // ... and phase rows
 
     f32x16 acc[TM][TN];
     float dbacc[TM];
@@ -1435,16 +1446,16 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
     float4 ra[NLD], rb[NLD];
     // The loop body is branch-free: the prefetch of "chunk c+2" and the staging of "chunk c+1" are
     // clamped to the last chunk instead of being skipped (the redundant copies are never read).
-    // panel rows are npad*4 bytes apart: one fixed per-thread byte offset per staging pass, the chunk
-    // offset is a scalar (no per-load 64-bit address arithmetic on the VALU, which the f32 MFMA shares)
-    const int panel_bytes = (int)((int64_t)QP * a.npad * 4);
+    // thread e fetches 16 bytes at e * 16 of the quadrant's rows; the chunk offset is a scalar (no per-load 64-bit address
+    // arithmetic on the VALU, which the f32 MFMA shares)
+    const int panel_bytes = (int)((int64_t)FP * a.npad * 4) - (NQ - 1) * QP * 128;      // to the end of the last chunk's rows of the last quadrant
     const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void *)Dl, 0, panel_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc((void *)Zl, 0, panel_bytes, 0x00020000);
     int voffs[NLD];
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
         const int e = tid + 512 * i;
-        voffs[i] = (e >> 3) * (int)(a.npad * 4) + (e & 7) * 16;
+        voffs[i] = e * 16;
     }
 #define WG_ISSUE(cc)                                                                              \
     _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                             \
@@ -1452,8 +1463,8 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
         ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);                                                  \
         rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);                                                  \
         if (FULL || e < QP * 8) {                                                                 \
-            ra[i] = bload4(rsD, voffs[i], (int)((cc) * 128));                                     \
-            rb[i] = bload4(rsZ, voffs[i], (int)((cc) * 128));                                     \
+            ra[i] = bload4(rsD, voffs[i], (int)((cc) * (FP * 128)));                                     \
+            rb[i] = bload4(rsZ, voffs[i], (int)((cc) * (FP * 128)));                                     \
         }                                                                                         \
     }
 #define WG_STAGE_A(buf, i)                                                                        \
@@ -1627,19 +1638,23 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_x3(const WgradArgs a)
             for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
     float bsum[NLD] = {0.f, 0.f, 0.f, 0.f};
     float4 ra[NLD], rb[NLD];
+#ifdef BRIEF_X3W_NOLOAD      // diagnostic builds (timing only, results are garbage): no memory traffic / no MFMAs / no staging
+    const int panel_bytes = 0;
+#else
     const int panel_bytes = (int)((int64_t)FP * a.npad * 4);
+#endif
     const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void *)Dl, 0, panel_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc((void *)Zl, 0, panel_bytes, 0x00020000);
     int voffs[NLD];
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
         const int e = tid + 512 * i;
-        voffs[i] = (e >> 3) * (int)(a.npad * 4) + (e & 7) * 16;
+        voffs[i] = e * 16;
     }
 #define X3W_ISSUE(cc)                                                                             \
     _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                             \
-        ra[i] = bload4(rsD, voffs[i], (int)((cc) * 128));                                         \
-        rb[i] = bload4(rsZ, voffs[i], (int)((cc) * 128));                                         \
+        ra[i] = bload4(rsD, voffs[i], (int)((cc) * (FP * 128)));                                         \
+        rb[i] = bload4(rsZ, voffs[i], (int)((cc) * (FP * 128)));                                         \
     }
     // four f32 values of one row -> 4 hi + 4 lo bf16 (8 + 8 bytes) in the row's hi / lo halves
 #define X3W_PUT(dst_, v_)                                                                         \
@@ -1674,6 +1689,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_x3(const WgradArgs a)
     for (int64_t c = c0; c < c1; ++c) {
         const int cur = (int)(c - c0) & 1;
         const float *As = smem + cur * 2 * PANEL, *Bs = As + PANEL;
+#ifndef BRIEF_X3W_NOMFMA
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             X3Frag ah[TM], al[TM], bh[TN], bl[TN];
@@ -1698,9 +1714,14 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_x3(const WgradArgs a)
                     acc[i][jn] = MFMA_X3(al[i].v, bh[jn].v, acc[i][jn]);
                 }
         }
+#endif
         // stage chunk c + 1 (its loads were issued an iteration ago), then request chunk c + 2
         const bool fresh = c + 1 < c1;
+#ifndef BRIEF_X3W_NOSTAGE
         X3W_STAGE(cur ^ 1, fresh)
+#else
+        if (fresh) bsum[0] += ra[0].x + rb[0].x + ra[1].x + rb[1].x + ra[2].x + rb[2].x + ra[3].x + rb[3].x;
+#endif
         {
             const int64_t cn = c + 2 < c1 ? c + 2 : c1 - 1;
             X3W_ISSUE(cn)
@@ -2223,7 +2244,7 @@ static int fused_grid(const brief_siren_desc &d, int64_t n, bool train)
     const int nt = brief_nt(d);
     const int64_t tiles = (n + brief_wg_samples(nt) - 1) / brief_wg_samples(nt);
     // resident workgroups per CU = what the kernel's launch bounds were compiled for (BRIEF_WG_PER_CU: diagnostics)
-    const int wpe = g_wg_per_cu_set ? g_wg_per_cu : (train ? (d.precision == BRIEF_PREC_BF16X3 ? 2 : fused_train_wpe(nt)) : (nt > 8 ? 2 : 3));
+    const int wpe = g_wg_per_cu_set ? g_wg_per_cu : (train ? (d.precision == BRIEF_PREC_BF16X3 ? BRIEF_X3_WPE : fused_train_wpe(nt)) : (nt > 8 ? 2 : 3));
     const int64_t cap = (int64_t)kCUs * (train && nt > 8 ? 1 : wpe);      // TRAIN > 8 tiles: 512-register kernel, one workgroup per CU
     return (int)(tiles < cap ? (tiles > 0 ? tiles : 1) : cap);
 }

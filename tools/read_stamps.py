@@ -8,7 +8,7 @@ from brief_pytorch_amd.networks import SIREN
 from brief_pytorch_amd.fit import Fitter
 torch.manual_seed(0)
 pop = 256**3
-m = SIREN(features=256, layers=5, w0=20).to('cuda')
+m = SIREN(features=256, layers=5, w0=20, precision=os.environ.get('STAMP_PREC', 'fp32')).to('cuda')
 tv = torch.rand(pop, 1, device='cuda') * 100
 fit = Fitter(m, tv, (256,256,256), sample_size=100000)
 for _ in range(int(os.environ.get("STAMP_STEPS", "600"))): fit.step()      # steady state: the first steps after idle run at ~1.85 GHz
