@@ -1637,7 +1637,8 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_x3(const WgradArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
     float bsum[NLD] = {0.f, 0.f, 0.f, 0.f};
-    float4 ra[NLD], rb[NLD];
+    u32x4 ra[NLD], rb[NLD];      // kept as whole 128-bit tuples: as float4 structs the loop-carried components were shuffled
+                                 // through copies behind s_waitcnt at the loop end, i.e. no prefetch across iterations
 #ifdef BRIEF_X3W_NOLOAD      // diagnostic builds (timing only, results are garbage): no memory traffic / no MFMAs / no staging
     const int panel_bytes = 0;
 #else
@@ -1651,16 +1652,17 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_x3(const WgradArgs a)
         const int e = tid + 512 * i;
         voffs[i] = e * 16;
     }
+#define X3F(u_) __uint_as_float(u_)
 #define X3W_ISSUE(cc)                                                                             \
     _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                             \
-        ra[i] = bload4(rsD, voffs[i], (int)((cc) * (FP * 128)));                                         \
-        rb[i] = bload4(rsZ, voffs[i], (int)((cc) * (FP * 128)));                                         \
+        ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsD, voffs[i], (int)((cc) * (FP * 128)), 0);       \
+        rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsZ, voffs[i], (int)((cc) * (FP * 128)), 0);       \
     }
     // four f32 values of one row -> 4 hi + 4 lo bf16 (8 + 8 bytes) in the row's hi / lo halves
 #define X3W_PUT(dst_, v_)                                                                         \
     {                                                                                             \
         union { uint2 u; __bf16 h[4]; } ph_, pl_;                                                 \
-        const float f_[4] = {(v_).x, (v_).y, (v_).z, (v_).w};                                     \
+        const float f_[4] = {__uint_as_float((v_).x), __uint_as_float((v_).y), __uint_as_float((v_).z), __uint_as_float((v_).w)}; \
         _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                        \
             ph_.h[j_] = (__bf16)f_[j_];                                                           \
             pl_.h[j_] = (__bf16)(f_[j_] - (float)ph_.h[j_]);                                      \
@@ -1673,10 +1675,10 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_x3(const WgradArgs a)
         const int e = tid + 512 * i;                                                              \
         float *pa_ = smem + (buf) * 2 * PANEL + (e >> 3) * LDSW + (e & 7) * 2;                    \
         X3W_PUT(pa_, ra[i])                                                                       \
-        if (count_) bsum[i] += (ra[i].x + ra[i].y) + (ra[i].z + ra[i].w);                         \
-        float4 h_;                                                                                \
-        h_.x = BRIEF_SIN_REV(rb[i].x); h_.y = BRIEF_SIN_REV(rb[i].y);                             \
-        h_.z = BRIEF_SIN_REV(rb[i].z); h_.w = BRIEF_SIN_REV(rb[i].w);                             \
+        if (count_) bsum[i] += (X3F(ra[i].x) + X3F(ra[i].y)) + (X3F(ra[i].z) + X3F(ra[i].w));     \
+        u32x4 h_;                                                                                 \
+        h_.x = __float_as_uint(BRIEF_SIN_REV(X3F(rb[i].x))); h_.y = __float_as_uint(BRIEF_SIN_REV(X3F(rb[i].y))); \
+        h_.z = __float_as_uint(BRIEF_SIN_REV(X3F(rb[i].z))); h_.w = __float_as_uint(BRIEF_SIN_REV(X3F(rb[i].w))); \
         X3W_PUT(pa_ + PANEL, h_)                                                                  \
     }
     X3W_ISSUE(c0)
@@ -1689,7 +1691,13 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_x3(const WgradArgs a)
     for (int64_t c = c0; c < c1; ++c) {
         const int cur = (int)(c - c0) & 1;
         const float *As = smem + cur * 2 * PANEL, *Bs = As + PANEL;
-#ifndef BRIEF_X3W_NOMFMA
+        // Chunk c + 1 is staged (its loads were issued an iteration ago) and chunk c + 2 requested BETWEEN this chunk's MFMA groups:
+        // a bf16 MFMA hides ~4 VALU instructions of its own wave (profiles/r03_coissue.md), so the 16 groups of three MFMAs
+        // carry the 4 x 4 staging sub-steps (pack delta | sines | pack h | next loads) instead of a separate VALU phase.  The
+        // staged buffer is the one nobody reads this iteration.
+        const float flag = c + 1 < c1 ? 1.0f : 0.0f;        // the clamped re-staging of the last chunk does not count in the bias sums
+        const int64_t cn = c + 2 < c1 ? c + 2 : c1 - 1;
+        u32x4 hs = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             X3Frag ah[TM], al[TM], bh[TN], bl[TN];
@@ -1709,26 +1717,46 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_x3(const WgradArgs a)
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int jn = 0; jn < TN; ++jn) {
+#ifndef BRIEF_X3W_NOMFMA
                     acc[i][jn] = MFMA_X3(ah[i].v, bh[jn].v, acc[i][jn]);
                     acc[i][jn] = MFMA_X3(ah[i].v, bl[jn].v, acc[i][jn]);
                     acc[i][jn] = MFMA_X3(al[i].v, bh[jn].v, acc[i][jn]);
-                }
-        }
 #endif
-        // stage chunk c + 1 (its loads were issued an iteration ago), then request chunk c + 2
-        const bool fresh = c + 1 < c1;
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int g = ks * (TM * TN) + i * TN + jn, slot = g >> 2, sub = g & 3;      // compile-time after unrolling
+                    const int e = tid + 512 * slot;
+                    float *pa_ = smem + (cur ^ 1) * 2 * PANEL + (e >> 3) * LDSW + (e & 7) * 2;
 #ifndef BRIEF_X3W_NOSTAGE
-        X3W_STAGE(cur ^ 1, fresh)
+                    // (the empty asm statements make the loop-carried values the load tuples themselves: left to the SLP vectoriser they
+                    //  were component pairs across slots, copied into place behind s_waitcnt vmcnt(0) at the end of every iteration)
+                    if (sub == 0) {
+                        asm volatile("" : "+v"(ra[slot]));
+                        X3W_PUT(pa_, ra[slot])
+                        bsum[slot] += flag * ((X3F(ra[slot].x) + X3F(ra[slot].y)) + (X3F(ra[slot].z) + X3F(ra[slot].w)));
+                    } else if (sub == 1) {
+                        asm volatile("" : "+v"(rb[slot]));
+                        hs.x = __float_as_uint(BRIEF_SIN_REV(X3F(rb[slot].x))); hs.y = __float_as_uint(BRIEF_SIN_REV(X3F(rb[slot].y)));
+                        hs.z = __float_as_uint(BRIEF_SIN_REV(X3F(rb[slot].z))); hs.w = __float_as_uint(BRIEF_SIN_REV(X3F(rb[slot].w)));
+                    } else if (sub == 2) {
+                        X3W_PUT(pa_ + PANEL, hs)
+                    } else {
+                        ra[slot] = __builtin_amdgcn_raw_buffer_load_b128(rsD, voffs[slot], (int)(cn * (FP * 128)), 0);
+                        rb[slot] = __builtin_amdgcn_raw_buffer_load_b128(rsZ, voffs[slot], (int)(cn * (FP * 128)), 0);
+                    }
 #else
-        if (fresh) bsum[0] += ra[0].x + rb[0].x + ra[1].x + rb[1].x + ra[2].x + rb[2].x + ra[3].x + rb[3].x;
+                    if (sub == 3) {
+                        bsum[slot] += flag * (X3F(ra[slot].x) + X3F(rb[slot].x));
+                        ra[slot] = __builtin_amdgcn_raw_buffer_load_b128(rsD, voffs[slot], (int)(cn * (FP * 128)), 0);
+                        rb[slot] = __builtin_amdgcn_raw_buffer_load_b128(rsZ, voffs[slot], (int)(cn * (FP * 128)), 0);
+                    }
 #endif
-        {
-            const int64_t cn = c + 2 < c1 ? c + 2 : c1 - 1;
-            X3W_ISSUE(cn)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
         }
         lds_barrier();
     }
 #undef X3W_ISSUE
+#undef X3F
 #undef X3W_PUT
 #undef X3W_STAGE
     float *slab = a.slabs + ((int64_t)(l - 1) * a.nsplit + split) * ((int64_t)FP * FP + FP);
