@@ -86,8 +86,8 @@ struct FusedArgs {
     GridArgs grid;
     int loss_kind;
     float thr, beta, inv_count;
-    float *Z;            // [(L-2)][FP][npad]   phases (om z reduced to revolutions) of layers 0..L-3
-    float *D;            // [(L-2)][FP][npad]   deltas of layers 1..L-2
+    float *Z;            // [(L-2)][npad/32][FP][32]   phases (om z reduced to revolutions) of layers 0..L-3, tile-blocked: a 32-sample tile's rows are 128 B apart
+    float *D;            // [(L-2)][npad/32][FP][32]   deltas of layers 1..L-2, same layout
     int64_t npad;
     float *rec;          // [gridDim.x*4][BRIEF_REC_FLOATS]
     int64_t n_begin, n_end;   // bf16 path: the sample range of this launch (body / tail launches)
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256, TRAIN ? (PREC == 2 ? BRIEF_X3_WPE : fused_trai
     const float4 *W0p = reinterpret_cast<const float4 *>(pk + brief_pk_w0(d));
     const __amdgpu_buffer_rsrc_t rs_pk =
         __builtin_amdgcn_make_buffer_rsrc((void *)pk, 0, (int)(brief_pk_count(d) * 4), 0x00020000);
-    const int stash_bytes = (a.diag & 1) ? 0 : (int)((int64_t)K::FP * npad * 4);   // one [FP][npad] panel (host checks < 2^31)
+    const int stash_bytes = (a.diag & 1) ? 0 : (int)((int64_t)K::FP * npad * 4);   // one layer's plane (host checks < 2^31)
 
     // head weights -> LDS once per workgroup (every lane needs all of them in the head dot product)
     {

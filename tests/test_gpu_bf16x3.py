@@ -4,6 +4,8 @@ loss traces 1e-4 against the reference's goldens / the oracle), which the bf16 m
 bit-identical to fp32; the decode kernels are the fp32 ones (bit-identical output)."""
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -134,3 +136,43 @@ def test_full_size_step_and_trace_of_the_headline_shape():
     print("bf16x3 full-size trace over %d steps: max relative error %.2e" % (steps, err.max()))
     assert err.max() < 1e-4
 
+
+
+def test_singletask_bf16x3_option_matches_the_fp32_run(tmp_path):
+    """Compress.precision: bf16x3 through NFGR.compress: fp32 weight files, side info records the precision, the stored artefact
+    decodes to the stored volume; the 150-step fit lands where the fp32 fit of the same seed lands (PSNR within 0.05 dB: the two
+    paths agree to ~1e-5 per step, the fit has not had time to diverge)"""
+    from brief_pytorch_amd import config
+    from brief_pytorch_amd.framework import NFGR, MyLogger
+    from brief_pytorch_amd.synthetic import make_volume
+    from brief_pytorch_amd.tool import read_img, save_img
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    vol = make_volume((16, 32, 32), seed=3)
+    path = str(tmp_path / "v.tif")
+    save_img(path, vol)
+    psnr = {}
+    for prec in ("fp32", "bf16x3"):
+        opt = config.load(os.path.join(root, "opt", "SingleTask", "default.yaml"))
+        cf = opt.CompressFramework
+        cf.Compress.max_steps = 150
+        cf.Compress.checkpoints = "none"
+        cf.Compress.param.filesize_ratio = 0
+        cf.Compress.param.given_size = 4.0 * SIREN.calc_param_count(3, 1, 160, 4)
+        cf.Module.phi.layers = 4
+        cf.Compress.precision = prec
+        opt.Log.outputs_dir = str(tmp_path / ("outputs_" + prec))
+        opt.Log.time = False
+        Log = MyLogger(**opt.Log)
+        torch.manual_seed(42)
+        fw = NFGR(cf, Log=Log)
+        res = fw.compress(path)
+        psnr[prec] = res[150]["psnr"]
+        if prec == "bf16x3":
+            sdir = os.path.join(Log.logdir, "steps150")
+            side = config.load(os.path.join(sdir, "compressed", "sideinfos.yaml"))
+            assert side["phi_precision"] == "bf16x3" and side["phi_features"] == 160
+            assert os.path.getsize(os.path.join(sdir, "compressed", "module", "weight-1-160-160")) == 160 * 160 * 4
+            again = NFGR.decompress(config.to_opt({"CompressFramework": cf}), os.path.join(sdir, "compressed", "module"), dict(side))
+            assert np.array_equal(again, read_img(os.path.join(sdir, "decompressed", "v_decompressed.tif")))
+    print("150-step SingleTask fit: fp32 %.3f dB, bf16x3 %.3f dB" % (psnr["fp32"], psnr["bf16x3"]))
+    assert psnr["fp32"] > 25 and abs(psnr["fp32"] - psnr["bf16x3"]) < 0.05
