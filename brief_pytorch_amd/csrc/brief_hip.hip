@@ -206,17 +206,19 @@ __device__ __forceinline__ void chain(f32x16 (&acc)[KCfg<NT>::MTW], __amdgpu_buf
     constexpr int smul = 1024;
     float4 areg[NIT][K::MTW];
     float4 breg[NIT];
-    // padding is at most 31 features = the last three steps: only those carry a run-time check
+    // padding is at most 31 features = the last three steps: only those carry a run-time check (on their MFMAs)
 #pragma unroll
     for (int it = 0; it < PD; ++it)
 #pragma unroll
         for (int t = 0; t < K::MTW; ++t)
-            if ((K::EXACT || wm + K::WM * t < NT) && (it < NIT - 3 || it < kit)) areg[it][t] = bload4(rs, voff, soff_w + (K::WM * t * NT * 4 + it) * smul);
+            if (K::EXACT || wm + K::WM * t < NT) areg[it][t] = bload4(rs, voff, soff_w + (K::WM * t * NT * 4 + it) * smul);
     breg[0] = Xs[lane];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         if (it >= NIT - 3 && it >= kit) break;
-        if (it + PD < NIT && (it + PD < NIT - 3 || it + PD < kit)) {
+        // (the prefetch is not predicated on kit: behind a wave-uniform branch the s_waitcnt bookkeeping counts the load as possibly
+        //  missing and waits one step early — prefetch depth 3, 2, 1 over steps NIT-7 .. NIT-5; the padded steps hold zero fragments)
+        if (it + PD < NIT) {
 #pragma unroll
             for (int t = 0; t < K::MTW; ++t)
                 if (K::EXACT || wm + K::WM * t < NT) {
@@ -257,31 +259,60 @@ __device__ __forceinline__ void write_image(float4 *Xs, const f32x16 (&h)[KCfg<N
 }
 
 // ---------------------------------------------------------------------------------------------
-// BRIEF_PREC_BF16X3: split-precision hidden GEMMs.  x = hi + lo with hi = bf16(x), lo = bf16(x - hi) keeps ~16 significant bits
+// BRIEF_PREC_BF16X3: split-precision hidden GEMMs.  x = hi + lo with hi = bf16(x), lo = bf16(x - hi) keeps ~16 significant bits (fp16 halves, used by the forward chains: 22)
 // of x; a product of two such operands is hi.hi + hi.lo + lo.hi (the dropped lo.lo term is 2^-16 of the product), three
 // v_mfma_f32_32x32x16_bf16 with f32 accumulation where the exact path issues eight v_mfma_f32_32x32x2_f32: 96 instead of 512
 // matrix-pipe cycles per 32 x 32 x 16 block.  tools/bf16x3_emulation.py: forward 7.9e-6 of max|y| and gradients 1.0e-5 of a
 // tensor's max-abs against float64 on the 4x256 net (f32: 7e-7 / 4e-7; bands 2e-5 / 1e-4).  Same skeleton as the f32 path (32-sample
 // tiles, f32 stashes, f32 head / loss / skinny gradients / optimizer); only the image and the weight fragments change.
 typedef __bf16 x3_bf16x8 __attribute__((ext_vector_type(8)));
-union X3Frag { uint4 u; x3_bf16x8 v; };
+typedef _Float16 x3_f16x8 __attribute__((ext_vector_type(8)));
+union X3Frag { uint4 u; x3_bf16x8 v; x3_f16x8 f; };
 #define MFMA_X3(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#define MFMA_X3F(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+// The FORWARD chains use fp16 halves (11 + 11 significant bits: the phase a deep net accumulates stays at f32's own accuracy,
+// tools/fuzz_parity.py ... bf16x3): activations lie in [-1, 1] and the forward weight copies carry 2^6 on top of om / 2 pi so that
+// their lo halves stay fp16-normal (|w om / 2 pi| ~ sqrt(6 / F) / 2 pi); the epilogue multiplies the accumulator by 2^-6, exactly.
+// The BACKWARD chains and the weight-gradient GEMM keep bf16 halves: deltas span far more than fp16's 30 binades.
+#define BRIEF_X3_FWD_SCALE 64.0f
+#define BRIEF_X3_FWD_UNSCALE 0.015625f
+__device__ __forceinline__ void x3_split_f16(float x, uint16_t &hi, uint16_t &lo)
+{
+    union { _Float16 h; uint16_t u; } a, b;
+    a.h = (_Float16)x;
+    b.h = (_Float16)(x - (float)a.h);
+    hi = a.u; lo = b.u;
+}
+__device__ __forceinline__ void x3_split_bf16(float x, uint16_t &hi, uint16_t &lo)
+{
+    union { __bf16 h; uint16_t u; } a, b;
+    a.h = (__bf16)x;
+    b.h = (__bf16)(x - (float)a.h);
+    hi = a.u; lo = b.u;
+}
 
 // registers 8s .. 8s+7 of an accumulator tile -> the hi and lo bf16 fragments of k-step s (the next layer's B operand)
+template <bool F16>
 __device__ __forceinline__ void x3_pack(const f32x16 &x, int s, uint4 &hi, uint4 &lo)
 {
     X3Frag h, l;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const __bf16 b = (__bf16)x[8 * s + j];
-        h.v[j] = b;
-        l.v[j] = (__bf16)(x[8 * s + j] - (float)b);
+        if (F16) {
+            const _Float16 b = (_Float16)x[8 * s + j];
+            h.f[j] = b;
+            l.f[j] = (_Float16)(x[8 * s + j] - (float)b);
+        } else {
+            const __bf16 b = (__bf16)x[8 * s + j];
+            h.v[j] = b;
+            l.v[j] = (__bf16)(x[8 * s + j] - (float)b);
+        }
     }
     hi = h.u; lo = l.u;
 }
 
 // image layout: [hi | lo][kt][s][lane] x 16 B  (NT * 2 * 64 uint4 per half)
-template <int NT>
+template <int NT, bool F16>
 __device__ __forceinline__ void x3_write_image(uint4 *X16, const f32x16 (&h)[KCfg<NT>::MTW], int wm, int lane)
 {
     using K = KCfg<NT>;
@@ -292,7 +323,7 @@ __device__ __forceinline__ void x3_write_image(uint4 *X16, const f32x16 (&h)[KCf
 #pragma unroll
             for (int sx = 0; sx < 2; ++sx) {
                 uint4 hi, lo;
-                x3_pack(h[t], sx, hi, lo);
+                x3_pack<F16>(h[t], sx, hi, lo);
                 X16[(mt * 2 + sx) * 64 + lane] = hi;
                 X16[NT * 2 * 64 + (mt * 2 + sx) * 64 + lane] = lo;
             }
@@ -303,7 +334,7 @@ __device__ __forceinline__ void x3_write_image(uint4 *X16, const f32x16 (&h)[KCf
 // one layer's GEMM for the feature tiles this wave owns, three bf16 MFMAs per (A, B) fragment pair.
 // rs: descriptor over the hi | lo fragment regions; soff_layer: byte offset of the layer's Wf16 (or Wb16) block in the hi
 // region; lo_bytes: distance to the same block in the lo region.  kit: k-steps (of 16 features) that hold real features.
-template <int NT>
+template <int NT, bool F16>
 __device__ __forceinline__ void x3_chain(f32x16 (&acc)[KCfg<NT>::MTW], __amdgpu_buffer_rsrc_t rs, int soff_layer, int lo_bytes,
                                          const uint4 *X16, int wm, int lane, int kit)
 {
@@ -354,9 +385,15 @@ __device__ __forceinline__ void x3_chain(f32x16 (&acc)[KCfg<NT>::MTW], __amdgpu_
 #else
                     fah.u = ahi[it][t]; fal.u = alo[it][t];
 #endif
-                    acc[t] = MFMA_X3(fah.v, fbh.v, acc[t]);
-                    acc[t] = MFMA_X3(fah.v, fbl.v, acc[t]);
-                    acc[t] = MFMA_X3(fal.v, fbh.v, acc[t]);
+                    if (F16) {
+                        acc[t] = MFMA_X3F(fah.f, fbh.f, acc[t]);
+                        acc[t] = MFMA_X3F(fah.f, fbl.f, acc[t]);
+                        acc[t] = MFMA_X3F(fal.f, fbh.f, acc[t]);
+                    } else {
+                        acc[t] = MFMA_X3(fah.v, fbh.v, acc[t]);
+                        acc[t] = MFMA_X3(fah.v, fbl.v, acc[t]);
+                        acc[t] = MFMA_X3(fal.v, fbh.v, acc[t]);
+                    }
                 }
             }
         }
@@ -601,14 +638,16 @@ __global__ __launch_bounds__(256, TRAIN ? (PREC == 2 ? BRIEF_X3_WPE : fused_trai
                 for (int t = 0; t < K::MTW; ++t) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        acc[t][4 * q] = bnext[t][q].x; acc[t][4 * q + 1] = bnext[t][q].y;
-                        acc[t][4 * q + 2] = bnext[t][q].z; acc[t][4 * q + 3] = bnext[t][q].w;
+                        // (split precision: the forward weight halves carry 2^6, so does the bias the accumulator starts from)
+                        constexpr float bs = PREC == 2 ? BRIEF_X3_FWD_SCALE : 1.0f;
+                        acc[t][4 * q] = bs * bnext[t][q].x; acc[t][4 * q + 1] = bs * bnext[t][q].y;
+                        acc[t][4 * q + 2] = bs * bnext[t][q].z; acc[t][4 * q + 3] = bs * bnext[t][q].w;
                     }
                 }
                 // matrix work first: the wave inside a chain outranks its SIMD mate's epilogue (-0.5 % step time; the opposite
                 // order, epilogues first, costs +0.5 %: tools/ab_lib.sh, profiles/r02_issue_model.md)
                 if (TRAIN) __builtin_amdgcn_s_setprio(3);
-                if constexpr (PREC == 2) x3_chain<NT>(acc, rs_x3, (l - 1) * K::FP * K::FP * 4, x3_lo_bytes, X16, wm, lane, kit16);
+                if constexpr (PREC == 2) x3_chain<NT, true>(acc, rs_x3, (l - 1) * K::FP * K::FP * 4, x3_lo_bytes, X16, wm, lane, kit16);
                 else chain<NT>(acc, rs_pk, (int)(brief_pk_hidden(d, l) * 4), Xs, wm, lane, kit);
                 if (TRAIN) __builtin_amdgcn_s_setprio(0);
                 STAMP(1)
@@ -625,7 +664,8 @@ __global__ __launch_bounds__(256, TRAIN ? (PREC == 2 ? BRIEF_X3_WPE : fused_trai
                     // is what sin and cos are taken of, here and (TRAIN) again from the stash by the dgrad chain (cos) and by
                     // k_wgrad (sin).  One VALU instruction per element where the exact two-term reduction took five.
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[t][r] = __builtin_amdgcn_fractf(acc[t][r]);
+                    for (int r = 0; r < 16; ++r)
+                        acc[t][r] = __builtin_amdgcn_fractf(PREC == 2 && l > 0 ? acc[t][r] * BRIEF_X3_FWD_UNSCALE : acc[t][r]);
                     if (TRAIN && !last) {
                         const __amdgpu_buffer_rsrc_t rz =
                             __builtin_amdgcn_make_buffer_rsrc((void *)(a.Z + (int64_t)l * K::FP * npad), 0, stash_bytes, 0x00020000);
@@ -651,7 +691,7 @@ __global__ __launch_bounds__(256, TRAIN ? (PREC == 2 ? BRIEF_X3_WPE : fused_trai
                     }
                 }
             }
-            if constexpr (PREC == 2) x3_write_image<NT>(X16, hreg, wm, lane);
+            if constexpr (PREC == 2) x3_write_image<NT, true>(X16, hreg, wm, lane);
             else write_image<NT>(Xs, hreg, wm, lane);
             STAMP(3)
             lds_barrier();
@@ -860,7 +900,7 @@ __global__ __launch_bounds__(256, TRAIN ? (PREC == 2 ? BRIEF_X3_WPE : fused_trai
             if (ZPRE) FUSED_LOAD_Z()
             STAMP(7)
             lds_barrier();   // transpose scratch / previous chain finished with the image region
-            if constexpr (PREC == 2) x3_write_image<NT>(X16, dl, wm, lane);
+            if constexpr (PREC == 2) x3_write_image<NT, false>(X16, dl, wm, lane);
             else write_image<NT>(Xs, dl, wm, lane);
             lds_barrier();
             STAMP(8)
@@ -869,7 +909,7 @@ __global__ __launch_bounds__(256, TRAIN ? (PREC == 2 ? BRIEF_X3_WPE : fused_trai
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
             __builtin_amdgcn_s_setprio(3);
-            if constexpr (PREC == 2) x3_chain<NT>(acc, rs_x3, (l - 1) * K::FP * K::FP * 4 + K::FP * K::FP * 2, x3_lo_bytes, X16, wm, lane, kit16);
+            if constexpr (PREC == 2) x3_chain<NT, false>(acc, rs_x3, (l - 1) * K::FP * K::FP * 4 + K::FP * K::FP * 2, x3_lo_bytes, X16, wm, lane, kit16);
             else chain<NT>(acc, rs_pk, (int)((brief_pk_hidden(d, l) + K::FP * K::FP) * 4), Xs, wm, lane, kit);
             __builtin_amdgcn_s_setprio(0);
             STAMP(9)
@@ -1898,14 +1938,16 @@ __global__ __launch_bounds__(1024) void k_reduce(const ReduceArgs a, int nb_hidd
                     blk[(int64_t)FP * FP + frag_index(NT, i, o)] = pb;            // A-fragments of w0_{l-1} W^T
                 }
                 if (d.precision == BRIEF_PREC_BF16X3) {
-                    // hi + lo bf16 halves of the same two products (k_repack forms them the same way)
-                    __bf16 *h16 = reinterpret_cast<__bf16 *>(a.pk + brief_pk16_off(d, l));
-                    __bf16 *l16 = reinterpret_cast<__bf16 *>(a.pk + brief_pk16_off(d, l) + brief_pk16_region(d));
-                    const __bf16 fh = (__bf16)pf, bh = (__bf16)pb;
+                    // hi + lo halves of the same two products (k_repack forms them the same way)
+                    uint16_t *h16 = reinterpret_cast<uint16_t *>(a.pk + brief_pk16_off(d, l));
+                    uint16_t *l16 = reinterpret_cast<uint16_t *>(a.pk + brief_pk16_off(d, l) + brief_pk16_region(d));
+                    uint16_t fh, fl, bh, bl;
+                    x3_split_f16(BRIEF_X3_FWD_SCALE * pf, fh, fl);      // forward copy: fp16 halves of 2^6 om W / 2 pi
+                    x3_split_bf16(pb, bh, bl);                          // backward copy: bf16 halves of om W^T
                     h16[brief_frag16_index(NT, o, i)] = fh;
                     h16[(int64_t)FP * FP + brief_frag16_index(NT, i, o)] = bh;
-                    l16[brief_frag16_index(NT, o, i)] = (__bf16)(pf - (float)fh);
-                    l16[(int64_t)FP * FP + brief_frag16_index(NT, i, o)] = (__bf16)(pb - (float)bh);
+                    l16[brief_frag16_index(NT, o, i)] = fl;
+                    l16[(int64_t)FP * FP + brief_frag16_index(NT, i, o)] = bl;
                 } else if (d.precision == BRIEF_PREC_BF16) {
                     // the bf16 kernels read only the bf16 fragments below (and the f32 first layer, biases and head): the f32
                     // hidden fragment slots hold zeros (k_repack) and are never read in this mode — two scattered 4-byte stores
@@ -2005,10 +2047,18 @@ __global__ void k_repack(const brief_siren_desc d, const float *__restrict__ par
                 float w = 0.f;
                 // the backward copy carries om_{l-1}: delta_{l-1} = (om W_l^T delta_l) . cos(om z_{l-1}); the forward copy om_l / 2 pi
                 if (row < F && col < F) w = bwd ? brief_om_prev(d, l) * W[(int64_t)col * F + row] : brief_phase_scale(d, l) * W[(int64_t)row * F + col];
-                union { __bf16 h; uint16_t u; } cv;
-                cv.h = (__bf16)w;
-                if (lo_half) cv.h = (__bf16)(w - (float)cv.h);
-                word |= (uint32_t)cv.u << (16 * half);
+                uint16_t u16;
+                if (d.precision == BRIEF_PREC_BF16X3) {
+                    uint16_t hi16, lo16;
+                    if (bwd) x3_split_bf16(w, hi16, lo16);
+                    else x3_split_f16(BRIEF_X3_FWD_SCALE * w, hi16, lo16);
+                    u16 = lo_half ? lo16 : hi16;
+                } else {
+                    union { __bf16 h; uint16_t u; } cv;
+                    cv.h = (__bf16)w;
+                    u16 = cv.u;
+                }
+                word |= (uint32_t)u16 << (16 * half);
             }
         }
         reinterpret_cast<uint32_t *>(pk)[e] = word;

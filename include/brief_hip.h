@@ -42,9 +42,11 @@ typedef struct {
                           * loss, reductions and optimizer); activations/deltas are stashed as bf16.  The MI355X counterpart of the
                           * reference's low-precision mode (Compress.half, main.py:388-399), pinned by a PSNR band, not bitwise.
                           * BRIEF_PREC_BF16X3 (2), features <= 256: split precision — weights, activations and deltas of the hidden GEMMs
-                          * are split into hi + lo bf16 halves and every product is three bf16 MFMAs (hi.hi + hi.lo + lo.hi, f32
-                          * accumulate): ~16 significant bits per operand, held to the SAME oracle bands as BRIEF_PREC_F32 (forward 2e-5,
-                          * gradients 1e-4, traces 1e-4) but not bit-identical to it; never the default.  Decode runs the f32 kernels. */
+                          * are split into hi + lo 16-bit halves and every product is three 16-bit MFMAs (hi.hi + hi.lo + lo.hi, f32
+                          * accumulate): fp16 halves in the forward chains (22 significant bits), bf16 halves in the backward chains and
+                          * the weight-gradient GEMM (16 bits, bf16's exponent range).  Held to the SAME oracle bands as BRIEF_PREC_F32
+                          * (forward 2e-5, gradients 1e-4, traces 1e-4) but not bit-identical to it; never the default.  Decode runs the
+                          * f32 kernels.  Needs |w0 W / 2 pi| < 1000 for every hidden weight (fp16 range of the scaled forward copy). */
 } brief_siren_desc;
 enum { BRIEF_PREC_F32 = 0, BRIEF_PREC_BF16 = 1, BRIEF_PREC_BF16X3 = 2 };
 
