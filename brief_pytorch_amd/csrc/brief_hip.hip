@@ -331,18 +331,48 @@ __device__ __forceinline__ void x3_write_image(uint4 *X16, const f32x16 (&h)[KCf
     }
 }
 
-// one layer's GEMM for the feature tiles this wave owns, three bf16 MFMAs per (A, B) fragment pair.
-// rs: descriptor over the hi | lo fragment regions; soff_layer: byte offset of the layer's Wf16 (or Wb16) block in the hi
+#ifndef BRIEF_X3_PD
+#define BRIEF_X3_PD 2
+#endif
+// the first PD k-steps of a chain's A fragments, requested AHEAD of the stash traffic that precedes the chain: vector-memory
+// operations retire in order (stores count in vmcnt too), so fragments requested after an epilogue's 32 stash stores (or the
+// dgrad's 32 stores + 32 phase loads) make the chain's first MFMA wait for all of those
+template <int NT>
+struct X3Pre { uint4 hi[BRIEF_X3_PD][KCfg<NT>::MTW], lo[BRIEF_X3_PD][KCfg<NT>::MTW]; };
+
+#define X3_LOAD_INTO(dh_, dl_, it_)                                                                          \
+    _Pragma("unroll") for (int t = 0; t < K::MTW; ++t) {                                                     \
+        if (K::EXACT || wm + K::WM * t < NT) {                                                               \
+            const u32x4 vh = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff_w + (K::WM * t * NT * 2 + (it_)) * 1024, 0); \
+            const u32x4 vl = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff_w + soff_lo + (K::WM * t * NT * 2 + (it_)) * 1024, 0); \
+            dh_[t] = make_uint4(vh.x, vh.y, vh.z, vh.w);                                                     \
+            dl_[t] = make_uint4(vl.x, vl.y, vl.z, vl.w);                                                     \
+        }                                                                                                    \
+    }
+
+template <int NT>
+__device__ __forceinline__ void x3_preload(X3Pre<NT> &pre, __amdgpu_buffer_rsrc_t rs, int soff_layer, int lo_bytes, int wm, int lane)
+{
+    using K = KCfg<NT>;
+    const int voff = lane * 16;
+    int soff_w = soff_layer + wm * (NT * 2 * 1024);
+    asm volatile("" : "+s"(soff_w));
+    int soff_lo = lo_bytes;
+    asm volatile("" : "+s"(soff_lo));
+#pragma unroll
+    for (int it = 0; it < BRIEF_X3_PD; ++it) X3_LOAD_INTO(pre.hi[it], pre.lo[it], it)
+}
+
+// one layer's GEMM for the feature tiles this wave owns, three 16-bit MFMAs per (A, B) fragment pair (F16: fp16 halves, else bf16).
+// rs: descriptor over the hi | lo fragment regions; soff_layer: byte offset of the layer's forward (or backward) block in the hi
 // region; lo_bytes: distance to the same block in the lo region.  kit: k-steps (of 16 features) that hold real features.
+// pre: the first PD k-steps of A fragments (x3_preload with the same rs / soff_layer / lo_bytes).
 template <int NT, bool F16>
-__device__ __forceinline__ void x3_chain(f32x16 (&acc)[KCfg<NT>::MTW], __amdgpu_buffer_rsrc_t rs, int soff_layer, int lo_bytes,
+__device__ __forceinline__ void x3_chain(f32x16 (&acc)[KCfg<NT>::MTW], const X3Pre<NT> &pre, __amdgpu_buffer_rsrc_t rs, int soff_layer, int lo_bytes,
                                          const uint4 *X16, int wm, int lane, int kit)
 {
     using K = KCfg<NT>;
     constexpr int NIT = NT * 2;
-#ifndef BRIEF_X3_PD
-#define BRIEF_X3_PD 4
-#endif
     constexpr int PD = BRIEF_X3_PD;      // k-steps of A fragments (hi + lo: 4 KB per step and wave) in flight
     const int voff = lane * 16;
     int soff_w = soff_layer + wm * (NT * 2 * 1024);
@@ -351,25 +381,18 @@ __device__ __forceinline__ void x3_chain(f32x16 (&acc)[KCfg<NT>::MTW], __amdgpu_
     asm volatile("" : "+s"(soff_lo));
     uint4 ahi[NIT][K::MTW], alo[NIT][K::MTW];
     uint4 bhi[NIT], blo[NIT];
-#define X3_LOAD(it_)                                                                                         \
-    _Pragma("unroll") for (int t = 0; t < K::MTW; ++t) {                                                     \
-        if (K::EXACT || wm + K::WM * t < NT) {                                                               \
-            const u32x4 vh = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff_w + (K::WM * t * NT * 2 + (it_)) * 1024, 0); \
-            const u32x4 vl = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff_w + soff_lo + (K::WM * t * NT * 2 + (it_)) * 1024, 0); \
-            ahi[it_][t] = make_uint4(vh.x, vh.y, vh.z, vh.w);                                                \
-            alo[it_][t] = make_uint4(vl.x, vl.y, vl.z, vl.w);                                                \
-        }                                                                                                    \
-    }
     // The loads are NOT predicated on kit (the padded k-steps hold zero fragments and zero activations): behind a wave-uniform
     // branch the compiler's s_waitcnt bookkeeping joins the two paths pessimistically and waits for vmcnt(0) — the fragments
     // fetched PD steps ahead included — inside every k-step, which is a prefetch depth of one.  Only the MFMAs are skipped.
 #pragma unroll
-    for (int it = 0; it < PD; ++it) X3_LOAD(it)
+    for (int it = 0; it < PD; ++it)
+#pragma unroll
+        for (int t = 0; t < K::MTW; ++t) { ahi[it][t] = pre.hi[it][t]; alo[it][t] = pre.lo[it][t]; }
     bhi[0] = X16[lane]; blo[0] = X16[NT * 2 * 64 + lane];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
 #ifndef BRIEF_X3_NOLOAD      // diagnostic build: only the first PD k-steps of weight fragments are fetched (results are garbage)
-        if (it + PD < NIT) X3_LOAD(it + PD)
+        if (it + PD < NIT) X3_LOAD_INTO(ahi[it + PD], alo[it + PD], it + PD)
 #endif
         if (it + 1 < NIT) { bhi[it + 1] = X16[(it + 1) * 64 + lane]; blo[it + 1] = X16[NT * 2 * 64 + (it + 1) * 64 + lane]; }
         __builtin_amdgcn_sched_barrier(0);
@@ -398,8 +421,8 @@ __device__ __forceinline__ void x3_chain(f32x16 (&acc)[KCfg<NT>::MTW], __amdgpu_
             }
         }
     }
-#undef X3_LOAD
 }
+#undef X3_LOAD_INTO
 
 // ---------------------------------------------------------------------------------------------
 // Philox4x32-10 voxel-index stream (stands in for the CPU torch.randint of main.py:156)
@@ -593,6 +616,7 @@ __global__ __launch_bounds__(256, TRAIN ? (PREC == 2 ? BRIEF_X3_WPE : fused_trai
         f32x16 acc[K::MTW];
         f32x16 creg[K::MTW];   // w*cos(w z) of the last sine layer (TRAIN)
         f32x16 hreg[K::MTW];
+        X3Pre<PREC == 2 ? NT : 1> x3pre;      // PREC == 2: the next chain's first A fragments (see x3_preload)
         float4 bnext[K::MTW][4];   // next hidden layer's bias, fetched one epilogue ahead of its use
 #pragma unroll
         for (int t = 0; t < K::MTW; ++t) {
@@ -647,13 +671,14 @@ __global__ __launch_bounds__(256, TRAIN ? (PREC == 2 ? BRIEF_X3_WPE : fused_trai
                 // matrix work first: the wave inside a chain outranks its SIMD mate's epilogue (-0.5 % step time; the opposite
                 // order, epilogues first, costs +0.5 %: tools/ab_lib.sh, profiles/r02_issue_model.md)
                 if (TRAIN) __builtin_amdgcn_s_setprio(3);
-                if constexpr (PREC == 2) x3_chain<NT, true>(acc, rs_x3, (l - 1) * K::FP * K::FP * 4, x3_lo_bytes, X16, wm, lane, kit16);
+                if constexpr (PREC == 2) x3_chain<NT, true>(acc, x3pre, rs_x3, (l - 1) * K::FP * K::FP * 4, x3_lo_bytes, X16, wm, lane, kit16);
                 else chain<NT>(acc, rs_pk, (int)(brief_pk_hidden(d, l) * 4), Xs, wm, lane, kit);
                 if (TRAIN) __builtin_amdgcn_s_setprio(0);
                 STAMP(1)
                 lds_barrier();   // every wave is done reading the previous image
                 STAMP(2)
             }
+            if constexpr (PREC == 2) { if (!last) x3_preload<NT>(x3pre, rs_x3, l * K::FP * K::FP * 4, x3_lo_bytes, wm, lane); }      // ahead of this epilogue's stash stores
             if (!last && !(TRAIN && fused_lean_p(NT, PREC))) FUSED_LOAD_BIAS(l + 1)   // lands while this epilogue computes its sines
             // epilogue: stash z, h = sin(om z) (+ c = om cos(om z) on the last sine layer)
 #pragma unroll
@@ -875,6 +900,7 @@ __global__ __launch_bounds__(256, TRAIN ? (PREC == 2 ? BRIEF_X3_WPE : fused_trai
             const __amdgpu_buffer_rsrc_t rd =
                 __builtin_amdgcn_make_buffer_rsrc((void *)(a.D + (int64_t)(l - 1) * K::FP * npad), 0, stash_bytes, 0x00020000);
             const int voff_s = (int)(n0 * (K::FP * 4)) + ln * 4 + hi * 4 * 128;
+            if constexpr (PREC == 2) x3_preload<NT>(x3pre, rs_x3, (l - 1) * K::FP * K::FP * 4 + K::FP * K::FP * 2, x3_lo_bytes, wm, lane);      // ahead of the delta stores and phase loads
 #pragma unroll
             for (int t = 0; t < K::MTW; ++t) {
                 const int mt = wm + K::WM * t;
@@ -909,7 +935,7 @@ __global__ __launch_bounds__(256, TRAIN ? (PREC == 2 ? BRIEF_X3_WPE : fused_trai
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
             __builtin_amdgcn_s_setprio(3);
-            if constexpr (PREC == 2) x3_chain<NT, false>(acc, rs_x3, (l - 1) * K::FP * K::FP * 4 + K::FP * K::FP * 2, x3_lo_bytes, X16, wm, lane, kit16);
+            if constexpr (PREC == 2) x3_chain<NT, false>(acc, x3pre, rs_x3, (l - 1) * K::FP * K::FP * 4 + K::FP * K::FP * 2, x3_lo_bytes, X16, wm, lane, kit16);
             else chain<NT>(acc, rs_pk, (int)((brief_pk_hidden(d, l) + K::FP * K::FP) * 4), Xs, wm, lane, kit);
             __builtin_amdgcn_s_setprio(0);
             STAMP(9)
