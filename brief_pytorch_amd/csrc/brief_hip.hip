@@ -1766,12 +1766,14 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_x3(const WgradArgs a)
         u32x4 hs = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            X3Frag ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const float *p_ = As + (32 * (wmk * TM + i) + ln) * LDSW + 8 * ks + 4 * hi;      // dwords: (16 ks + 8 hi) samples x 2 B
-                ah[i].u = *reinterpret_cast<const uint4 *>(p_);
-                al[i].u = *reinterpret_cast<const uint4 *>(p_ + 16);
+            // A fragments one row-tile ahead of their MFMAs (2 x 8 registers), B fragments for the whole k-step (16): with all four row
+            // tiles' fragments resident (32) the allocator parked two of the prefetched operand tuples elsewhere and copied them back
+            // behind s_waitcnt vmcnt(3) at the end of every iteration
+            X3Frag ah[2], al[2], bh[TN], bl[TN];
+            {
+                const float *p_ = As + (32 * (wmk * TM) + ln) * LDSW + 8 * ks + 4 * hi;           // dwords: (16 ks + 8 hi) samples x 2 B
+                ah[0].u = *reinterpret_cast<const uint4 *>(p_);
+                al[0].u = *reinterpret_cast<const uint4 *>(p_ + 16);
             }
 #pragma unroll
             for (int jn = 0; jn < TN; ++jn) {
@@ -1783,10 +1785,15 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_x3(const WgradArgs a)
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int jn = 0; jn < TN; ++jn) {
+                    if (jn == 0 && i + 1 < TM) {
+                        const float *p_ = As + (32 * (wmk * TM + i + 1) + ln) * LDSW + 8 * ks + 4 * hi;
+                        ah[(i + 1) & 1].u = *reinterpret_cast<const uint4 *>(p_);
+                        al[(i + 1) & 1].u = *reinterpret_cast<const uint4 *>(p_ + 16);
+                    }
 #ifndef BRIEF_X3W_NOMFMA
-                    acc[i][jn] = MFMA_X3(ah[i].v, bh[jn].v, acc[i][jn]);
-                    acc[i][jn] = MFMA_X3(ah[i].v, bl[jn].v, acc[i][jn]);
-                    acc[i][jn] = MFMA_X3(al[i].v, bh[jn].v, acc[i][jn]);
+                    acc[i][jn] = MFMA_X3(ah[i & 1].v, bh[jn].v, acc[i][jn]);
+                    acc[i][jn] = MFMA_X3(ah[i & 1].v, bl[jn].v, acc[i][jn]);
+                    acc[i][jn] = MFMA_X3(al[i & 1].v, bh[jn].v, acc[i][jn]);
 #endif
                     __builtin_amdgcn_sched_barrier(0);
                     const int g = ks * (TM * TN) + i * TN + jn, slot = g >> 2, sub = g & 3;      // compile-time after unrolling
