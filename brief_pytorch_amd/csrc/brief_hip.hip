@@ -1605,7 +1605,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
         }
         STAMP(1)
         {
-            const int64_t cn = c + 2 < c1 ? c + 2 : c1 - 1;
+            const int64_t cn = c + 2 < c1 ? c + 2 : c1 - 1, cn1 = c + 1 < c1 ? c + 1 : c1 - 1;
             WG_ISSUE(cn)
         }
         STAMP(2)
@@ -1678,6 +1678,9 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
 // per fragment pair.  Panel rows are [32 samples hi | 32 samples lo | pad] = 144 B, the f32 kernel's conflict-free 36-dword
 // stride; a fragment is 16 B of a row (8 consecutive samples).  Bias gradients: row sums of the f32 deltas, taken by the threads
 // that stage them.  Same slab format as k_wgrad: k_reduce does not know the difference.
+#ifndef BRIEF_X3W_DLY
+#define BRIEF_X3W_DLY 0
+#endif
 __global__ __launch_bounds__(512, 2) void k_wgrad_x3(const WgradArgs a)
 {
     constexpr int FP = 256, QT = 8, WNk = 4, TM = 4, TN = 2, LDSW = 36, NLD = 4, PANEL = FP * LDSW;
@@ -1719,10 +1722,11 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_x3(const WgradArgs a)
         voffs[i] = e * 16;
     }
 #define X3F(u_) __uint_as_float(u_)
+#define X3W_LD(rs_, base_, voff_, soff_) __builtin_amdgcn_raw_buffer_load_b128(rs_, voff_, soff_, 0)
 #define X3W_ISSUE(cc)                                                                             \
     _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                             \
-        ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsD, voffs[i], (int)((cc) * (FP * 128)), 0);       \
-        rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsZ, voffs[i], (int)((cc) * (FP * 128)), 0);       \
+        ra[i] = X3W_LD(rsD, Dl, voffs[i], (int)((cc) * (FP * 128)));       \
+        rb[i] = X3W_LD(rsZ, Zl, voffs[i], (int)((cc) * (FP * 128)));       \
     }
     // four f32 values of one row -> 4 hi + 4 lo bf16 (8 + 8 bytes) in the row's hi / lo halves
 #define X3W_PUT(dst_, v_)                                                                         \
@@ -1762,7 +1766,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_x3(const WgradArgs a)
         // carry the 4 x 4 staging sub-steps (pack delta | sines | pack h | next loads) instead of a separate VALU phase.  The
         // staged buffer is the one nobody reads this iteration.
         const float flag = c + 1 < c1 ? 1.0f : 0.0f;        // the clamped re-staging of the last chunk does not count in the bias sums
-        const int64_t cn = c + 2 < c1 ? c + 2 : c1 - 1;
+        const int64_t cn = c + 2 < c1 ? c + 2 : c1 - 1, cn1 = c + 1 < c1 ? c + 1 : c1 - 1;
         u32x4 hs = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -1805,22 +1809,38 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_x3(const WgradArgs a)
                     if (sub == 0) {
                         asm volatile("" : "+v"(ra[slot]));
                         X3W_PUT(pa_, ra[slot])
-                        bsum[slot] += flag * ((X3F(ra[slot].x) + X3F(ra[slot].y)) + (X3F(ra[slot].z) + X3F(ra[slot].w)));
+                        // (kept scalar and opaque: vectorised across slots, the sums were formed in place in the registers of
+                        //  ra[0] / ra[2], whose reloads then went elsewhere and were copied back behind s_waitcnt vmcnt(3) at
+                        //  the end of every iteration — five of the eight loads just issued had to land before the next chunk)
+                        float rs_ = (X3F(ra[slot].x) + X3F(ra[slot].y)) + (X3F(ra[slot].z) + X3F(ra[slot].w));
+                        asm volatile("" : "+v"(rs_));
+                        bsum[slot] += flag * rs_;
                     } else if (sub == 1) {
                         asm volatile("" : "+v"(rb[slot]));
                         hs.x = __float_as_uint(BRIEF_SIN_REV(X3F(rb[slot].x))); hs.y = __float_as_uint(BRIEF_SIN_REV(X3F(rb[slot].y)));
                         hs.z = __float_as_uint(BRIEF_SIN_REV(X3F(rb[slot].z))); hs.w = __float_as_uint(BRIEF_SIN_REV(X3F(rb[slot].w)));
                     } else if (sub == 2) {
                         X3W_PUT(pa_ + PANEL, hs)
-                    } else {
-                        ra[slot] = __builtin_amdgcn_raw_buffer_load_b128(rsD, voffs[slot], (int)(cn * (FP * 128)), 0);
-                        rb[slot] = __builtin_amdgcn_raw_buffer_load_b128(rsZ, voffs[slot], (int)(cn * (FP * 128)), 0);
+                    }
+                    // the freed slot is re-requested BRIEF_X3W_DLY groups later (wrapping into the next iteration, ahead of the slot's
+                    // staging there): the memory system delivers more with less in flight (tools/hbm_read_ubench.hip: 6.4 TB/s at
+                    // 16-32 KB per CU, 5.5 at 64 KB and above)
+                    {
+                        const int gl = (g + 16 - 3 - BRIEF_X3W_DLY) & 15;      // the group whose slot is due now (compile-time after unrolling)
+                        if ((gl & 3) == 0) {
+                            const int sl = gl >> 2;
+                            const int64_t cl = (4 * sl + 3 + BRIEF_X3W_DLY < 16) ? cn : cn1;
+                            ra[sl] = X3W_LD(rsD, Dl, voffs[sl], (int)(cl * (FP * 128)));
+                            rb[sl] = X3W_LD(rsZ, Zl, voffs[sl], (int)(cl * (FP * 128)));
+                        }
                     }
 #else
                     if (sub == 3) {
-                        bsum[slot] += flag * (X3F(ra[slot].x) + X3F(rb[slot].x));
-                        ra[slot] = __builtin_amdgcn_raw_buffer_load_b128(rsD, voffs[slot], (int)(cn * (FP * 128)), 0);
-                        rb[slot] = __builtin_amdgcn_raw_buffer_load_b128(rsZ, voffs[slot], (int)(cn * (FP * 128)), 0);
+                        float rs_ = X3F(ra[slot].x) + X3F(rb[slot].x);
+                        asm volatile("" : "+v"(rs_));
+                        bsum[slot] += flag * rs_;
+                        ra[slot] = X3W_LD(rsD, Dl, voffs[slot], (int)(cn * (FP * 128)));
+                        rb[slot] = X3W_LD(rsZ, Zl, voffs[slot], (int)(cn * (FP * 128)));
                     }
 #endif
                     __builtin_amdgcn_sched_barrier(0);
@@ -1829,6 +1849,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_x3(const WgradArgs a)
         lds_barrier();
     }
 #undef X3W_ISSUE
+#undef X3W_LD
 #undef X3F
 #undef X3W_PUT
 #undef X3W_STAGE
@@ -2348,6 +2369,7 @@ static const int g_wg_per_cu = env_int("BRIEF_WG_PER_CU", BRIEF_TRAIN_WPE, 1, 4)
 static const bool g_wg_per_cu_set = getenv("BRIEF_WG_PER_CU") != nullptr;
 static const int g_stagger = env_int("BRIEF_STAGGER", 0, 0, 64);      // start delay per residency slot: measured neutral with two and with three workgroups per CU (profiles/r03_wg_timeline.md), off
 static const int g_diag = env_int("BRIEF_DIAG", 0, 0, 255);
+static const int g_wgrad_repeat = env_int("BRIEF_WGRAD_REPEAT", 1, 1, 8);      // diagnostics: k_wgrad_x3 launched this many times per step (reads of data that k_fused has just written vs data at rest)
 static const int g_reduce_sg_big = env_int("BRIEF_REDUCE_SG_BIG", 4, 1, 64);
 static const int g_reduce_sg_small = env_int("BRIEF_REDUCE_SG", 0, 0, 64);      // diagnostics: k_reduce threads per hidden parameter behind k_small (power of two; 0 = by slab count)
 static int fused_grid(const brief_siren_desc &d, int64_t n, bool train)
@@ -2783,7 +2805,8 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
         wa.stamps = ws + wl.rec + (int64_t)kCUs * kRecWgsPerCu * 4 * BRIEF_REC_FLOATS - 256 * 8 * 8;   // tail of the record region (diagnostics)
         const int blocks = nsplit * (d->layers - 2) * wgrad_nq(nt) * wgrad_nq(nt);
         if (d->precision == BRIEF_PREC_BF16X3) {
-            hipLaunchKernelGGL(k_wgrad_x3, dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(8), st, wa);
+            for (int rep = 0; rep < g_wgrad_repeat; ++rep)      // BRIEF_WGRAD_REPEAT (diagnostics): the launch is idempotent
+                hipLaunchKernelGGL(k_wgrad_x3, dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(8), st, wa);
         } else
 #define BRIEF_CASE(NTV)                                                                                    \
     case NTV:                                                                                              \
