@@ -222,7 +222,7 @@ def launch_ranks(args):
     sys.exit(subprocess.call(cmd))
 
 
-def timed_config(name, L, F, dims, sampler, n, precision, steps, tgt=None, seed=7):
+def timed_config(name, L, F, dims, sampler, n, precision, steps, tgt=None, seed=7, decode=False):
     """one BASELINE configuration on this GPU: `steps` optimizer steps in one brief_siren_fit call, wall clock bracketed by
     synchronize, the dominant kernel timed by HIP events inside the library (as for the headline)."""
     L_ = _lib.lib()
@@ -255,7 +255,19 @@ def timed_config(name, L, F, dims, sampler, n, precision, steps, tgt=None, seed=
     kms = tot_ms.value / max(launches.value, 1)
     small = F <= 64 and precision == "fp32"              # k_small is the whole train step but the reduction
     kflop = (train_f if small else fused_f) * nb
-    return {"workload": name, "layers": L, "features": F, "volume": list(dims), "samples_per_step": nb, "dtype": DTYPES[precision],
+    dec = {}
+    if decode:
+        # decode_grid of the whole block with this net (output left in HBM, de-normalise + uint16 cast fused), as for the headline
+        out = net.decode_grid(dims, out_kind="u16", scale=(0.0, 100.0), vrange=(0.0, 65535.0))
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        net.decode_grid(dims, out_kind="u16", scale=(0.0, 100.0), vrange=(0.0, 65535.0), out=out)
+        torch.cuda.synchronize()
+        t_dec = time.perf_counter() - t2
+        nvox = float(np.prod(dims))
+        dec = {"decode_kernel": {"seconds": t_dec, "voxels_per_s": nvox / t_dec, "tflops": nvox * flops_per_sample(L, F)[2] / t_dec / 1e12}}
+        del out
+    return {**dec, "workload": name, "layers": L, "features": F, "volume": list(dims), "samples_per_step": nb, "dtype": DTYPES[precision],
             "steps": steps, "ms_per_step": el * 1e3 / steps, "voxels_per_s": nb * steps / el,
             "step_tflops": train_f * nb / (el / steps) / 1e12, "step_frac": train_f * nb / (el / steps) / 1e12 / peak,
             "kernel": "k_small" if small else {"fp32": "k_fused", "bf16x3": "k_fused<8,true,2>", "bf16": "k16 (body + tail launches)"}[precision],
@@ -498,7 +510,7 @@ def main():
             cfgs["c2_512cube_4x256_bf16x3"] = timed_config("the headline workload (SingleTask 512^3, SIREN 4x256, randompoint sample_size=100000) under precision="
                                                            "bf16x3: hidden GEMMs as three bf16 MFMAs per product on hi/lo operand halves, f32 accumulate and stashes; "
                                                            "passes the fp32 parity bands (tests/test_gpu_bf16x3.py); priced against bf16 peak / 3; not the metric",
-                                                           LAYERS, FEATURES, BLOCK, "randompoint", SAMPLE, "bf16x3", 200, tgt=tgt)
+                                                           LAYERS, FEATURES, BLOCK, "randompoint", SAMPLE, "bf16x3", 200, tgt=tgt, decode=True)
             extra["configs"] = cfgs
             # ---- PSNR against bitrate on the 512^3 volume: three net sizes, --encode-steps steps each
             pts = [rate_point(128, tgt, vol, vmin, vmax, steps_done),

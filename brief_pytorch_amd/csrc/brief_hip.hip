@@ -488,10 +488,13 @@ constexpr bool fused_lean(int NT) { return BRIEF_LEAN && NT == 8; }
 #ifndef BRIEF_X3_WPE
 #define BRIEF_X3_WPE 2
 #endif
+#ifndef BRIEF_X3_FWD_WPE
+#define BRIEF_X3_FWD_WPE 2      // resident workgroups per CU of the split-precision inference kernel (3: 168 VGPRs + 92 B of scratch, 3 % slower)
+#endif
 constexpr bool fused_lean_p(int NT, int PREC) { return PREC == 2 ? (bool)BRIEF_X3_LEAN : fused_lean(NT); }
 constexpr int fused_train_wpe(int NT) { return NT > 8 ? 1 : (NT <= 4 || fused_lean(NT) ? (BRIEF_TRAIN_WPE > 3 ? BRIEF_TRAIN_WPE : 3) : BRIEF_TRAIN_WPE); }
 template <int NT, bool TRAIN, int PREC = 0 /* 0: f32 MFMA; 2: BRIEF_PREC_BF16X3 hidden GEMMs (x3_chain) */>
-__global__ __launch_bounds__(256, TRAIN ? (PREC == 2 ? BRIEF_X3_WPE : fused_train_wpe(NT)) : (NT > 8 ? 2 : 3)) void k_fused(const FusedArgs a)
+__global__ __launch_bounds__(256, TRAIN ? (PREC == 2 ? BRIEF_X3_WPE : fused_train_wpe(NT)) : (PREC == 2 ? BRIEF_X3_FWD_WPE : (NT > 8 ? 2 : 3))) void k_fused(const FusedArgs a)
 {
 #ifdef BRIEF_STAMPS
     float st_acc[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -2369,6 +2372,7 @@ static const int g_wg_per_cu = env_int("BRIEF_WG_PER_CU", BRIEF_TRAIN_WPE, 1, 4)
 static const bool g_wg_per_cu_set = getenv("BRIEF_WG_PER_CU") != nullptr;
 static const int g_stagger = env_int("BRIEF_STAGGER", 0, 0, 64);      // start delay per residency slot: measured neutral with two and with three workgroups per CU (profiles/r03_wg_timeline.md), off
 static const int g_diag = env_int("BRIEF_DIAG", 0, 0, 255);
+static const int g_x3_decode = env_int("BRIEF_X3_DECODE", 1, 0, 1);      // 0 (diagnostics): BRIEF_PREC_BF16X3 nets are evaluated by the f32 forward kernel
 static const int g_wgrad_repeat = env_int("BRIEF_WGRAD_REPEAT", 1, 1, 8);      // diagnostics: k_wgrad_x3 launched this many times per step (reads of data that k_fused has just written vs data at rest)
 static const int g_reduce_sg_big = env_int("BRIEF_REDUCE_SG_BIG", 4, 1, 64);
 static const int g_reduce_sg_small = env_int("BRIEF_REDUCE_SG", 0, 0, 64);      // diagnostics: k_reduce threads per hidden parameter behind k_small (power of two; 0 = by slab count)
@@ -2377,7 +2381,7 @@ static int fused_grid(const brief_siren_desc &d, int64_t n, bool train)
     const int nt = brief_nt(d);
     const int64_t tiles = (n + brief_wg_samples(nt) - 1) / brief_wg_samples(nt);
     // resident workgroups per CU = what the kernel's launch bounds were compiled for (BRIEF_WG_PER_CU: diagnostics)
-    const int wpe = g_wg_per_cu_set ? g_wg_per_cu : (train ? (d.precision == BRIEF_PREC_BF16X3 ? BRIEF_X3_WPE : fused_train_wpe(nt)) : (nt > 8 ? 2 : 3));
+    const int wpe = g_wg_per_cu_set ? g_wg_per_cu : (train ? (d.precision == BRIEF_PREC_BF16X3 ? BRIEF_X3_WPE : fused_train_wpe(nt)) : (d.precision == BRIEF_PREC_BF16X3 && g_x3_decode ? BRIEF_X3_FWD_WPE : (nt > 8 ? 2 : 3)));
     const int64_t cap = (int64_t)kCUs * (train && nt > 8 ? 1 : wpe);      // TRAIN > 8 tiles: 512-register kernel, one workgroup per CU
     return (int)(tiles < cap ? (tiles > 0 ? tiles : 1) : cap);
 }
@@ -2550,15 +2554,17 @@ template <bool TRAIN>
 static int launch_fused(const FusedArgs &fa, int grid, hipStream_t st)
 {
     const int nt = brief_nt(fa.d);
-    if (TRAIN && fa.d.precision == BRIEF_PREC_BF16X3) {
-        // split-precision hidden GEMMs (FP = 256): the f32 kernel's skeleton with x3_chain / x3_write_image, + 2 KB of head partials
+    if (fa.d.precision == BRIEF_PREC_BF16X3 && (TRAIN || g_x3_decode)) {
+        // split-precision hidden GEMMs (FP = 256): the f32 kernel's skeleton with x3_chain / x3_write_image, + 2 KB of head partials.
+        // Inference (forward / decode_grid) runs the same forward chains on fp16 halves: yhat within ~2e-6 of max|y| of the f32
+        // kernel's (BRIEF_X3_DECODE=0: the f32 kernel instead, diagnostics)
         const size_t lds = sizeof(float) * FusedLds<8>::TOTAL + 4 * 32 * sizeof(float4);
         static bool attr_x3 = false;
         if (!attr_x3) {
-            HIP_TRY(hipFuncSetAttribute((const void *)k_fused<8, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIP_TRY(hipFuncSetAttribute((const void *)k_fused<8, TRAIN, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr_x3 = true;
         }
-        hipLaunchKernelGGL((k_fused<8, true, 2>), dim3(grid), dim3(256), lds, st, fa);
+        hipLaunchKernelGGL((k_fused<8, TRAIN, 2>), dim3(grid), dim3(256), lds, st, fa);
         HIP_TRY(hipGetLastError());
         return 0;
     }

@@ -45,8 +45,8 @@ typedef struct {
                           * are split into hi + lo 16-bit halves and every product is three 16-bit MFMAs (hi.hi + hi.lo + lo.hi, f32
                           * accumulate): fp16 halves in the forward chains (22 significant bits), bf16 halves in the backward chains and
                           * the weight-gradient GEMM (16 bits, bf16's exponent range).  Held to the SAME oracle bands as BRIEF_PREC_F32
-                          * (forward 2e-5, gradients 1e-4, traces 1e-4) but not bit-identical to it; never the default.  Decode runs the
-                          * f32 kernels.  Needs |w0 W / 2 pi| < 1000 for every hidden weight (fp16 range of the scaled forward copy). */
+                          * (forward 2e-5, gradients 1e-4, traces 1e-4) but not bit-identical to it; never the default.  Inference
+                          * (brief_siren_forward / _decode) runs the same fp16-halves forward chains (~1e-6 from the f32 kernel).  Needs |w0 W / 2 pi| < 1000 for every hidden weight (fp16 range of the scaled forward copy). */
 } brief_siren_desc;
 enum { BRIEF_PREC_F32 = 0, BRIEF_PREC_BF16 = 1, BRIEF_PREC_BF16X3 = 2 };
 

@@ -1,7 +1,7 @@
 """BRIEF_PREC_BF16X3 (`precision="bf16x3"`): split-precision hidden GEMMs — every operand a hi + lo pair of 16-bit halves (fp16 in the
 forward chains, bf16 in the backward chains and the weight-gradient GEMM), three 16-bit MFMAs per product — held to the SAME bands as the fp32 path (forward 2e-5 of max|y|, loss 1e-5, every gradient tensor 1e-4 of its max-abs,
 loss traces 1e-4 against the reference's goldens / the oracle), which the bf16 mode (bands 1e-2) is not.  Never the default and not
-bit-identical to fp32; the decode kernels are the fp32 ones (bit-identical output)."""
+bit-identical to fp32; inference runs the same forward chains (fp16 halves), ~2e-6 from the f32 kernel."""
 import ctypes as C
 
 import os
@@ -110,12 +110,29 @@ def test_random_configurations_vs_oracle_at_the_fp32_bands():
     print("bf16x3 random walk, 60 configurations: worst yhat %.2e (band 2e-5), worst gradient tensor %.2e of a 1e-4 band" % (worst_f, worst_g))
 
 
-def test_forward_and_decode_are_the_fp32_kernels():
-    a, _, _ = _net(5, 200, seed=3, precision="bf16x3")
+def test_forward_and_decode_on_the_split_precision_kernel():
+    """inference (forward / decode_grid) of a bf16x3 net runs the forward chains on fp16 halves: against the oracle inside the fp32
+    band (2e-5; measured ~2e-6, the f32 kernel's own distance), within 5e-6 of the f32 kernel, bit-reproducible; the fused
+    de-normalise + truncating uint16 cast then differs from the f32 kernel's by at most one code, in a small share of the voxels"""
+    a, d, p = _net(5, 200, seed=3, precision="bf16x3")
     b, _, _ = _net(5, 200, seed=3, precision="fp32")
-    x = torch.from_numpy(np.random.default_rng(1).uniform(-1, 1, size=(777, 3)).astype(np.float32)).to(DEV)
-    assert torch.equal(a.forward(x), b.forward(x))
-    assert torch.equal(a.decode_grid((9, 10, 11)), b.decode_grid((9, 10, 11)))
+    xh = np.random.default_rng(1).uniform(-1, 1, size=(7777, 3)).astype(np.float32)
+    x = torch.from_numpy(xh).to(DEV)
+    ya, yb = a.forward(x), b.forward(x)
+    yo = O.forward(d, p, xh)
+    ea, eb = relerr(ya.cpu().numpy(), yo), relerr(yb.cpu().numpy(), yo)
+    print("forward against the oracle: bf16x3 %.2e, fp32 %.2e; against each other %.2e" % (ea, eb, relerr(ya.cpu().numpy(), yb.cpu().numpy())))
+    assert ea < 2e-5 and relerr(ya.cpu().numpy(), yb.cpu().numpy()) < 5e-6
+    assert torch.equal(ya, a.forward(x))
+    dims = (40, 50, 60)
+    fa, fb = a.decode_grid(dims), b.decode_grid(dims)
+    assert relerr(fa.cpu().numpy(), O.forward(d, p, O.grid_coords(dims))) < 2e-5 and relerr(fa.cpu().numpy(), fb.cpu().numpy()) < 5e-6
+    lo, hi = float(fb.min()), float(fb.max())
+    ua = a.decode_grid(dims, out_kind="u16", scale=(lo, hi), vrange=(0.0, 65535.0)).cpu().numpy().astype(np.int64)
+    ub = b.decode_grid(dims, out_kind="u16", scale=(lo, hi), vrange=(0.0, 65535.0)).cpu().numpy().astype(np.int64)
+    diff = np.abs(ua - ub)
+    print("uint16 decode over the net's full range: %.1f %% of the voxels differ, by at most %d code(s)" % (100.0 * np.mean(diff > 0), diff.max()))
+    assert diff.max() <= 1 and np.mean(diff > 0) < 0.25
 
 
 def test_trace_against_the_reference_golden_and_fit_loop_identities(golden):

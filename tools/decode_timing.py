@@ -1,9 +1,9 @@
-"""scratch: decode throughput (forward-only kernels) fp32 vs bf16"""
+"""scratch: decode throughput (forward-only kernels) fp32 vs bf16 vs bf16x3"""
 import sys, torch, time
 sys.path.insert(0, '.')
 from brief_pytorch_amd.networks import SIREN
 for (L, F) in ((5, 256), (9, 512)):
-    for prec in ('fp32', 'bf16'):
+    for prec in ('fp32', 'bf16') + (('bf16x3',) if F <= 256 else ()):
         torch.manual_seed(0)
         m = SIREN(features=F, layers=L, w0=20, precision=prec).to('cuda')
         dims = (256, 256, 256)
