@@ -331,6 +331,19 @@ __device__ __forceinline__ void x3_write_image(uint4 *X16, const f32x16 (&h)[KCf
     }
 }
 
+// one feature tile's 16 accumulator registers -> its two k-steps of hi | lo fragments in the image
+template <bool F16>
+__device__ __forceinline__ void x3_write_tile(uint4 *X16, const f32x16 &h, int mt, int lane)
+{
+#pragma unroll
+    for (int sx = 0; sx < 2; ++sx) {
+        uint4 hi, lo;
+        x3_pack<F16>(h, sx, hi, lo);
+        X16[(mt * 2 + sx) * 64 + lane] = hi;
+        X16[8 * 2 * 64 + (mt * 2 + sx) * 64 + lane] = lo;
+    }
+}
+
 #ifndef BRIEF_X3_PD
 #define BRIEF_X3_PD 2
 #endif
@@ -1009,6 +1022,482 @@ __global__ __launch_bounds__(256, TRAIN ? (PREC == 2 ? BRIEF_X3_WPE : fused_trai
             rec[BRIEF_REC_STAMPS + 14] = (float)(__builtin_amdgcn_s_getreg(4 | (0 << 6) | (15 << 11)) & 0xFFFF);  // HW_REG_HW_ID[15:0]: wave, simd, pipe, cu[11:8], sh[12], se[15:13]
 #endif
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// BRIEF_PREC_BF16X3 train step, 64-sample tiles: k_fused<8,true,2>'s job with every A (weight) fragment used against TWO B
+// fragments (two 32-sample halves of the tile).  A 32-sample tile pulls 256 KB of hi | lo fragments per layer through the CU's
+// 64 B/clk vector-memory path — 4 096 cycles per tile-layer against 3 072 cycles of MFMA issue, the chains of the 32-sample
+// kernel ran at 7.7 k cycles per layer; here a wave owns 2 feature tiles x 2 sample halves (64 accumulator registers) and the
+// same bytes feed twice the MFMAs.  Same arithmetic per sample as k_fused<8,true,2> (fp16 halves forward, bf16 halves
+// backward, f32 stashes in the same tile-blocked planes, same records for k_reduce); only the order in which a workgroup's
+// samples enter its skinny-gradient sums differs.  LDS: two hi | lo images (64 KB) + G + head weights + head partials = 76 KB,
+// two workgroups per CU.
+struct X3TLds {
+    static constexpr int IMG_FLOATS = 2 * 4 * 64 * 33;          // two sample halves x (hi | lo) images = 64 KB, aliased by the transposed scratch [2 halves][4 waves][64 rows][33] = 66 KB
+    static constexpr int G_OFF = IMG_FLOATS;
+    static constexpr int HW_OFF = G_OFF + 4 * 256;
+    static constexpr int PART_OFF = HW_OFF + 4 * 256 + 4;       // head partials [2 halves][4 waves][32] float4
+    static constexpr int TOTAL = PART_OFF + 2 * 4 * 32 * 4;
+};
+
+template <bool F16>
+__device__ __forceinline__ void x3_chain2(f32x16 (&acc)[2][2], const X3Pre<8> &pre, __amdgpu_buffer_rsrc_t rs, int soff_layer, int lo_bytes,
+                                          const uint4 *X16, int wm, int lane, int kit, bool two)
+{
+    constexpr int NT = 8, NIT = 16, PD = BRIEF_X3_PD, HALF = 2 * NT * 2 * 64;      // uint4 per sample half (hi + lo)
+    using K = KCfg<8>;
+    const int voff = lane * 16;
+    int soff_w = soff_layer + wm * (NT * 2 * 1024);
+    asm volatile("" : "+s"(soff_w));
+    int soff_lo = lo_bytes;
+    asm volatile("" : "+s"(soff_lo));
+    uint4 ahi[NIT][2], alo[NIT][2];
+    uint4 bhi[NIT][2], blo[NIT][2];
+#pragma unroll
+    for (int it = 0; it < PD; ++it)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { ahi[it][t] = pre.hi[it][t]; alo[it][t] = pre.lo[it][t]; }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) { bhi[0][h] = X16[h * HALF + lane]; blo[0][h] = X16[h * HALF + NT * 2 * 64 + lane]; }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        if (it + PD < NIT) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const u32x4 vh = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff_w + (K::WM * t * NT * 2 + it + PD) * 1024, 0);
+                const u32x4 vl = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff_w + soff_lo + (K::WM * t * NT * 2 + it + PD) * 1024, 0);
+                ahi[it + PD][t] = make_uint4(vh.x, vh.y, vh.z, vh.w);
+                alo[it + PD][t] = make_uint4(vl.x, vl.y, vl.z, vl.w);
+            }
+        }
+        // (B fragments are read in the step that uses them: a step ahead they cost 16 more registers, and with those the persistent
+        //  per-tile state no longer fits beside the chain — 25 spilled dwords, reloaded from scratch in every head / gradient phase)
+        if (it > 0) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                bhi[it][h] = X16[h * HALF + it * 64 + lane];
+                blo[it][h] = X16[h * HALF + NT * 2 * 64 + it * 64 + lane];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (it < kit) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                X3Frag fah, fal;
+                fah.u = ahi[it][t]; fal.u = alo[it][t];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (h == 1 && !two) continue;      // a single half-tile at the end of a workgroup's run (wave-uniform; no loads inside)
+                    X3Frag fbh, fbl;
+                    fbh.u = bhi[it][h]; fbl.u = blo[it][h];
+                    if (F16) {
+                        acc[h][t] = MFMA_X3F(fah.f, fbh.f, acc[h][t]);
+                        acc[h][t] = MFMA_X3F(fah.f, fbl.f, acc[h][t]);
+                        acc[h][t] = MFMA_X3F(fal.f, fbh.f, acc[h][t]);
+                    } else {
+                        acc[h][t] = MFMA_X3(fah.v, fbh.v, acc[h][t]);
+                        acc[h][t] = MFMA_X3(fah.v, fbl.v, acc[h][t]);
+                        acc[h][t] = MFMA_X3(fal.v, fbh.v, acc[h][t]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void k_fused_x3(const FusedArgs a)
+{
+#ifdef BRIEF_STAMPS
+    float st_acc[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    long long st_last = clock64();
+    const long long st_c0 = st_last, st_r0 = wall_clock64();
+#endif
+    constexpr int NT = 8, FP = 256, HALF = 2 * NT * 2 * 64;
+    using K = KCfg<8>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    uint4 *X16 = reinterpret_cast<uint4 *>(smem);
+    float *T = smem;                       // aliases the images
+    float *G = smem + X3TLds::G_OFF;
+    float *HW = smem + X3TLds::HW_OFF;     // Whp[4][FP], bhp[4]
+    float4 *PART = reinterpret_cast<float4 *>(smem + X3TLds::PART_OFF);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hi = lane >> 5, ln = lane & 31;
+    const int wm = wave;
+    const brief_siren_desc &d = a.d;
+    const int L = d.layers, cin = d.cin, cout = d.cout;
+    const int kit16 = (d.features + 15) >> 4;
+    const int64_t npad = a.npad;
+    const float *pk = a.pk;
+    float *Tw = T + wave * 2 * (K::TROWS * 33);
+    float *Gw = G + wave * 256;
+    const float4 *W0p = reinterpret_cast<const float4 *>(pk + brief_pk_w0(d));
+    const __amdgpu_buffer_rsrc_t rs_x3 =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(a.pk + brief_pk16_off(a.d, 1)), 0, (int)(2 * brief_pk16_region(a.d) * 4), 0x00020000);
+    const int x3_lo_bytes = (int)(brief_pk16_region(a.d) * 4);
+    const int stash_bytes = (a.diag & 1) ? 0 : (int)((int64_t)FP * npad * 4);
+    {
+        const float *headp = pk + brief_pk_head(d);
+        for (int e = threadIdx.x; e < 4 * FP + 4; e += 256) HW[e] = headp[e];
+    }
+    lds_barrier();
+    float acc0[4] = {0.f, 0.f, 0.f, 0.f}, accWh[4] = {0.f, 0.f, 0.f, 0.f}, accbh[4] = {0.f, 0.f, 0.f, 0.f};
+    float lsum = 0.f;
+    // Work is dealt in 32-sample half-tiles walked two at a time.  With whole 64-sample tiles, 100 000 samples are 1 563 tiles for 512
+    // resident workgroups — 3.05 rounds, a fourth round at 5 % occupancy.  Instead: R = Hn / (2 G) full rounds of pairs, strided
+    // (round r: workgroup w takes half-tiles 2 (r G + w), +1 — the grid writes ONE moving window of the stash planes at a time;
+    // contiguous runs per workgroup, 512 scattered write streams, cost 20 k cycles per wave in the delta stores and 12 us in the
+    // k_wgrad that follows), then the Hr < 2 G left-over half-tiles as one more pair for the first Hr - G workgroups (if Hr > G)
+    // and a single (second half skipped) for the others that get one.
+    const int64_t Hn = (a.n + 31) >> 5;
+    const int64_t G_ = gridDim.x, w_ = blockIdx.x;
+    const int64_t R_ = Hn / (2 * G_), Hr = Hn - 2 * G_ * R_;
+    const int64_t npair_x = Hr > G_ ? Hr - G_ : 0;                          // workgroups whose extra is a pair
+    const int64_t nsing_x = Hr > G_ ? G_ - npair_x : Hr;                     // ... a single (the workgroups after those)
+    const int extra = w_ < npair_x ? 2 : (w_ < npair_x + nsing_x ? 1 : 0);
+    const int64_t ht_x = 2 * G_ * R_ + (w_ < npair_x ? 2 * w_ : 2 * npair_x + (w_ - npair_x));
+    for (int64_t it_ = 0; it_ < R_ + (extra ? 1 : 0); ++it_) {
+        const int64_t ht = it_ < R_ ? 2 * (it_ * G_ + w_) : ht_x;
+        const bool two = it_ < R_ || extra == 2;      // workgroup-uniform: the second half exists
+        // ---- sample inputs of both halves (kernarg scalars re-read per tile, as in k_fused)
+        typedef const __attribute__((address_space(4))) FusedArgs *kargs_f;
+        kargs_f ap = (kargs_f)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ap));
+        const int64_t *k_idx = ap->idx;
+        const float *k_tg = ap->targets, *k_wt = ap->weights, *k_co = ap->coords;
+        const uint64_t k_pop = ap->rng_pop, k_seed = ap->rng_seed, k_step = ap->rng_step;
+        const int64_t k_off = ap->offset;
+        GridArgs kg;
+        kg.ndim = ap->grid.ndim; kg.lo = ap->grid.lo; kg.hi = ap->grid.hi; kg.fast = ap->grid.fast;
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) { kg.dims[ax] = ap->grid.dims[ax]; kg.step[ax] = ap->grid.step[ax]; kg.magic[ax] = ap->grid.magic[ax]; }
+        float x0[2], x1[2], x2[2];
+        int64_t jidx[2];      // targets and loss weights are fetched at the loss (two workgroups per CU cover the latency; 16 registers less across the forward pass)
+        bool valid[2];
+        f32x16 acc[2][2];      // ONE 64-register array per wave: accumulators -> phases -> cos of the last layer -> deltas (in place throughout)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t n = (ht + h) * 32 + ln;
+            valid[h] = (h == 0 || two) && n < a.n;
+            int64_t j = 0;
+            if (valid[h]) j = k_idx ? k_idx[n] : (k_pop ? philox_index(n, k_pop, k_seed, k_step) : n + k_off);
+            x0[h] = 0.f; x1[h] = 0.f; x2[h] = 0.f;
+            jidx[h] = j;
+            if (valid[h]) {
+                if (k_co) {
+                    x0[h] = k_co[j * cin];
+                    x1[h] = k_co[j * cin + 1];
+                    if (cin == 3) x2[h] = k_co[j * cin + 2];
+                } else {
+                    grid_coords(kg, cin, j, x0[h], x1[h], x2[h]);
+                }
+            }
+        }
+        X3Pre<8> x3pre;
+        float4 bnext[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bnext[t][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+#define X3T_LOAD_BIAS(layer)                                                                            \
+    {                                                                                                   \
+        const float *bp_ = pk + brief_pk_hidden(d, (layer)) + 2 * FP * FP;                              \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                 \
+            const int mt = wm + 4 * t;                                                                  \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q)                                               \
+                bnext[t][q] = *reinterpret_cast<const float4 *>(bp_ + 32 * mt + 8 * q + 4 * hi);        \
+        }                                                                                               \
+    }
+        // ---- layer 0 (exact f32): z0 = W0 x + b0 as two K=2 MFMAs per feature tile and half
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float b0 = hi ? x1[h] : x0[h];
+            const float b1 = hi ? 1.0f : x2[h];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int mt = wm + 4 * t;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[h][t][r] = 0.f;
+                const float4 w = W0p[32 * mt + ln];
+                acc[h][t] = MFMA(hi ? w.y : w.x, b0, acc[h][t]);
+                acc[h][t] = MFMA(hi ? w.w : w.z, b1, acc[h][t]);
+            }
+        }
+        STAMP(0)
+        // ---- sine layers 0 .. L-2
+        for (int l = 0; l <= L - 2; ++l) {
+            const bool last = (l == L - 2);
+            if (l > 0) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            acc[h][t][4 * q] = BRIEF_X3_FWD_SCALE * bnext[t][q].x; acc[h][t][4 * q + 1] = BRIEF_X3_FWD_SCALE * bnext[t][q].y;
+                            acc[h][t][4 * q + 2] = BRIEF_X3_FWD_SCALE * bnext[t][q].z; acc[h][t][4 * q + 3] = BRIEF_X3_FWD_SCALE * bnext[t][q].w;
+                        }
+                __builtin_amdgcn_s_setprio(3);
+                x3_chain2<true>(acc, x3pre, rs_x3, (l - 1) * FP * FP * 4, x3_lo_bytes, X16, wm, lane, kit16, two);
+                __builtin_amdgcn_s_setprio(0);
+                STAMP(1)
+                lds_barrier();   // every wave is done reading the previous images
+                STAMP(2)
+            }
+            if (!last) {
+                x3_preload<8>(x3pre, rs_x3, l * FP * FP * 4, x3_lo_bytes, wm, lane);      // ahead of this epilogue's stash stores
+                X3T_LOAD_BIAS(l + 1)
+            }
+            float pph[2][4];      // (last layer) head partials of both halves
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) pph[h][c] = 0.f;
+                if (h == 1 && !two) continue;
+                const int voff = (int)(((ht + h) * 32) * (FP * 4)) + ln * 4 + hi * 4 * 128;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int mt = wm + 4 * t;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[h][t][r] = __builtin_amdgcn_fractf(l > 0 ? acc[h][t][r] * BRIEF_X3_FWD_UNSCALE : acc[h][t][r]);
+                    f32x16 hv;
+                    if (!last) {
+                        const __amdgpu_buffer_rsrc_t rz =
+                            __builtin_amdgcn_make_buffer_rsrc((void *)(a.Z + (int64_t)l * FP * npad), 0, stash_bytes, 0x00020000);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) bstore1(acc[h][t][r], rz, voff, (32 * mt + (r & 3) + 8 * (r >> 2)) * 128);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) hv[r] = BRIEF_SIN_REV(acc[h][t][r]);
+                        x3_write_tile<true>(X16 + h * HALF, hv, mt, lane);
+                    } else {
+                        // last sine layer: h feeds the head (from registers) and goes to this wave's transposed scratch for the head
+                        // gradients (the images are dead: every wave is past the last chain's barrier); cos(phase) replaces the phase
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) { hv[r] = BRIEF_SIN_REV(acc[h][t][r]); acc[h][t][r] = BRIEF_COS_REV(acc[h][t][r]); }
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            if (c < cout) {
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const float4 wv = *reinterpret_cast<const float4 *>(HW + c * FP + 32 * mt + 8 * q + 4 * hi);
+                                    pph[h][c] = __fmaf_rn(wv.x, hv[4 * q], pph[h][c]); pph[h][c] = __fmaf_rn(wv.y, hv[4 * q + 1], pph[h][c]);
+                                    pph[h][c] = __fmaf_rn(wv.z, hv[4 * q + 2], pph[h][c]); pph[h][c] = __fmaf_rn(wv.w, hv[4 * q + 3], pph[h][c]);
+                                }
+                            }
+                        }
+                        float *Th = T + (wave * 2 + h) * (K::TROWS * 33);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) Th[(32 * t + ROWMAP(r, hi)) * 33 + ln] = hv[r];
+                    }
+                }
+                if (last) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) pph[h][c] += __shfl_xor(pph[h][c], 32);
+                    if (hi == 0) PART[(h * 4 + wave) * 32 + ln] = make_float4(pph[h][0], pph[h][1], pph[h][2], pph[h][3]);
+                }
+            }
+            STAMP(3)
+            lds_barrier();      // images (or, last layer, the head partials) are published
+            STAMP(4)
+        }
+        // ---- head: the waves' partial dot products (taken from the exact f32 activations above), summed in wave order
+        float zo[2][4], yh[2][4], g[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float4 tot = PART[(h * 4) * 32 + ln];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const float4 v = PART[(h * 4 + w) * 32 + ln];
+                tot.x += v.x; tot.y += v.y; tot.z += v.z; tot.w += v.w;
+            }
+            const float tt[4] = {tot.x, tot.y, tot.z, tot.w};
+            const int64_t n = (ht + h) * 32 + ln;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                zo[h][c] = 0.f; yh[h][c] = 0.f; g[h][c] = 0.f;
+                if (c < cout) {
+                    zo[h][c] = tt[c] + HW[4 * FP + c];
+                    yh[h][c] = d.output_act ? brief_fast_sinf(d.w0_hidden * zo[h][c]) : zo[h][c];
+                }
+                // ---- loss and dloss/dyhat (main.py:176-191)
+                if (c < cout && valid[h]) {
+                    const float yvc = k_tg[jidx[h] * cout + c];
+                    float we = k_wt ? k_wt[jidx[h] * cout + c] : 1.0f;
+                    if (a.thr != 0.f && yh[h][c] <= a.thr) we = 1.0f;
+                    const float df = yh[h][c] - yvc;
+                    float li, gi;
+                    if (a.loss_kind == BRIEF_LOSS_L2) { li = df * df; gi = 2.0f * df; }
+                    else if (a.loss_kind == BRIEF_LOSS_SMOOTHL1) {
+                        const float ad = fabsf(df);
+                        if (ad < a.beta) { li = 0.5f * df * df / a.beta; gi = df / a.beta; }
+                        else { li = ad - 0.5f * a.beta; gi = df < 0.f ? -1.0f : 1.0f; }
+                    } else { li = 0.f; gi = 0.f; }
+                    if (wm == 0 && hi == 0) lsum += li * we;
+                    g[h][c] = a.loss_kind == BRIEF_LOSS_EXTERNAL ? yvc : gi * we * a.inv_count;      // external: targets ARE dL/dyhat
+                    if (d.output_act) g[h][c] *= d.w0_hidden * brief_fast_cosf(d.w0_hidden * zo[h][c]);
+                    if (a.yhat_out && wm == 0 && hi == 0) a.yhat_out[n * cout + c] = yh[h][c];
+                }
+            }
+        }
+        STAMP(5)
+        // ---- head gradients, one half after the other: transpose own h tiles through LDS (the scratch aliases the images: every
+        //      wave is past its last chain — the barrier above), lane <-> local feature
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h == 1 && !two) continue;      // (workgroup-uniform: the barriers below are skipped by every wave)
+            if (h) lds_barrier();      // the previous half's sums are done with G
+            if (hi == 0) *reinterpret_cast<float4 *>(Gw + ln * 4) = make_float4(g[h][0], g[h][1], g[h][2], g[h][3]);
+            lds_barrier();
+            {
+                float4 sW = make_float4(0.f, 0.f, 0.f, 0.f), sb = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float *trow = T + (wave * 2 + h) * (K::TROWS * 33) + lane * 33;
+                if (cout == 1) {
+#pragma unroll 8
+                    for (int s = 0; s < 32; ++s) {
+                        const float gv = Gw[s * 4];
+                        sW.x = __fmaf_rn(trow[s], gv, sW.x);
+                        sb.x += gv;
+                    }
+                } else {
+#pragma unroll 4
+                    for (int s = 0; s < 32; ++s) {
+                        const float hv = trow[s];
+                        const float4 gv = *reinterpret_cast<const float4 *>(Gw + s * 4);
+                        sW.x = __fmaf_rn(hv, gv.x, sW.x); sW.y = __fmaf_rn(hv, gv.y, sW.y);
+                        sW.z = __fmaf_rn(hv, gv.z, sW.z); sW.w = __fmaf_rn(hv, gv.w, sW.w);
+                        sb.x += gv.x; sb.y += gv.y; sb.z += gv.z; sb.w += gv.w;
+                    }
+                }
+                accWh[0] += sW.x; accWh[1] += sW.y; accWh[2] += sW.z; accWh[3] += sW.w;
+                accbh[0] += sb.x; accbh[1] += sb.y; accbh[2] += sb.z; accbh[3] += sb.w;
+            }
+        }
+        // ---- delta of the last sine layer: om cos(phase) * (Wh^T g); the om rides on g
+        {
+            const float om_top = (L - 2) == 0 ? d.w0_first : d.w0_hidden;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (h == 1 && !two) continue;
+                float gom[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) gom[c] = om_top * g[h][c];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int mt = wm + 4 * t;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            if (c < cout) {
+                                const float4 wv = *reinterpret_cast<const float4 *>(HW + c * FP + 32 * mt + 8 * q + 4 * hi);
+                                sacc.x = __fmaf_rn(wv.x, gom[c], sacc.x); sacc.y = __fmaf_rn(wv.y, gom[c], sacc.y);
+                                sacc.z = __fmaf_rn(wv.z, gom[c], sacc.z); sacc.w = __fmaf_rn(wv.w, gom[c], sacc.w);
+                            }
+                        }
+                        acc[h][t][4 * q] *= sacc.x; acc[h][t][4 * q + 1] *= sacc.y;
+                        acc[h][t][4 * q + 2] *= sacc.z; acc[h][t][4 * q + 3] *= sacc.w;
+                    }
+                }
+            }
+        }
+        STAMP(6)
+        // ---- dgrad chain: layers L-2 .. 1
+        for (int l = L - 2; l >= 1; --l) {
+            const __amdgpu_buffer_rsrc_t rd =
+                __builtin_amdgcn_make_buffer_rsrc((void *)(a.D + (int64_t)(l - 1) * FP * npad), 0, stash_bytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rzp =
+                __builtin_amdgcn_make_buffer_rsrc((void *)(a.Z + (int64_t)(l - 1) * FP * npad), 0, stash_bytes, 0x00020000);
+            x3_preload<8>(x3pre, rs_x3, (l - 1) * FP * FP * 4 + FP * FP * 2, x3_lo_bytes, wm, lane);      // ahead of the delta stores
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (h == 1 && !two) continue;
+                const int voff_s = (int)(((ht + h) * 32) * (FP * 4)) + ln * 4 + hi * 4 * 128;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int mt = wm + 4 * t;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) bstore1(acc[h][t][r], rd, voff_s, (32 * mt + (r & 3) + 8 * (r >> 2)) * 128);
+                }
+            }
+            STAMP(7)
+            lds_barrier();   // transpose scratch / previous chain finished with the image region
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                if (h == 0 || two) x3_write_image<8, false>(X16 + h * HALF, acc[h], wm, lane);
+            lds_barrier();
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[h][t][r] = 0.f;
+            STAMP(8)
+            __builtin_amdgcn_s_setprio(3);
+            x3_chain2<false>(acc, x3pre, rs_x3, (l - 1) * FP * FP * 4 + FP * FP * 2, x3_lo_bytes, X16, wm, lane, kit16, two);
+            __builtin_amdgcn_s_setprio(0);
+            STAMP(9)
+            // delta_{l-1} = acc * cos(phase_{l-1}): the phases come back from the stash after the chain (the SIMD's other wave covers it)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (h == 1 && !two) continue;
+                const int voff_s = (int)(((ht + h) * 32) * (FP * 4)) + ln * 4 + hi * 4 * 128;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int mt = wm + 4 * t;
+                    float zr[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) zr[r] = bload1(rzp, voff_s, (32 * mt + (r & 3) + 8 * (r >> 2)) * 128);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[h][t][r] *= BRIEF_COS_REV(zr[r]);
+                }
+            }
+        }
+        STAMP(7)
+        // ---- first-layer gradients from delta_0, one half after the other (lane <-> local feature)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h == 1 && !two) continue;
+            lds_barrier();
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Tw[(32 * t + ROWMAP(r, hi)) * 33 + ln] = acc[h][t][r];
+            if (hi == 1) *reinterpret_cast<float4 *>(Gw + 128 + ln * 4) = make_float4(x0[h], x1[h], x2[h], 1.0f);
+            lds_barrier();
+            float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float *trow = Tw + lane * 33;
+#pragma unroll 4
+            for (int s = 0; s < 32; ++s) {
+                const float dv = trow[s];
+                const float4 xv = *reinterpret_cast<const float4 *>(Gw + 128 + s * 4);
+                s0.x = __fmaf_rn(dv, xv.x, s0.x); s0.y = __fmaf_rn(dv, xv.y, s0.y);
+                s0.z = __fmaf_rn(dv, xv.z, s0.z); s0.w = __fmaf_rn(dv, xv.w, s0.w);
+            }
+            acc0[0] += s0.x; acc0[1] += s0.y; acc0[2] += s0.z; acc0[3] += s0.w;
+        }
+        lds_barrier();
+        STAMP(6)
+    }
+#undef X3T_LOAD_BIAS
+    float *rec = a.rec + ((int64_t)blockIdx.x * 4 + wave) * BRIEF_REC_FLOATS;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        rec[lane * 4 + c] = acc0[c];                        // dW0[f_local][x0,x1,x2,bias]
+        rec[BRIEF_REC_DWH + c * 128 + lane] = accWh[c];     // dWh[c][f_local]
+    }
+    for (int off = 32; off >= 1; off >>= 1) lsum += __shfl_xor(lsum, off);
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) rec[BRIEF_REC_DBH + c] = accbh[c];
+        rec[BRIEF_REC_LOSS] = lsum;
+#ifdef BRIEF_STAMPS
+        for (int i = 0; i < 10; ++i) rec[BRIEF_REC_STAMPS + i] = st_acc[i];
+        rec[BRIEF_REC_STAMPS + 10] = (float)(clock64() - st_c0);
+        rec[BRIEF_REC_STAMPS + 11] = (float)(wall_clock64() - st_r0);
+#endif
     }
 }
 
@@ -2372,14 +2861,22 @@ static const int g_wg_per_cu = env_int("BRIEF_WG_PER_CU", BRIEF_TRAIN_WPE, 1, 4)
 static const bool g_wg_per_cu_set = getenv("BRIEF_WG_PER_CU") != nullptr;
 static const int g_stagger = env_int("BRIEF_STAGGER", 0, 0, 64);      // start delay per residency slot: measured neutral with two and with three workgroups per CU (profiles/r03_wg_timeline.md), off
 static const int g_diag = env_int("BRIEF_DIAG", 0, 0, 255);
+static const int g_x3_t64 = env_int("BRIEF_X3_T64", 1, 0, 1);            // 0 (diagnostics): BRIEF_PREC_BF16X3 trains on the 32-sample kernel (k_fused<8,true,2>) instead of k_fused_x3
 static const int g_x3_decode = env_int("BRIEF_X3_DECODE", 1, 0, 1);      // 0 (diagnostics): BRIEF_PREC_BF16X3 nets are evaluated by the f32 forward kernel
 static const int g_wgrad_repeat = env_int("BRIEF_WGRAD_REPEAT", 1, 1, 8);      // diagnostics: k_wgrad_x3 launched this many times per step (reads of data that k_fused has just written vs data at rest)
 static const int g_reduce_sg_big = env_int("BRIEF_REDUCE_SG_BIG", 4, 1, 64);
 static const int g_reduce_sg_small = env_int("BRIEF_REDUCE_SG", 0, 0, 64);      // diagnostics: k_reduce threads per hidden parameter behind k_small (power of two; 0 = by slab count)
+// samples one workgroup tile covers: 32 per sample sub-tile; the split-precision TRAIN kernel walks 64-sample tiles
+static int64_t fused_wg_samples(const brief_siren_desc &d, bool train)
+{
+    (void)train;
+    return brief_wg_samples(brief_nt(d));      // (the split-precision TRAIN kernel deals 32-sample half-tiles too, and walks them in pairs)
+}
 static int fused_grid(const brief_siren_desc &d, int64_t n, bool train)
 {
     const int nt = brief_nt(d);
-    const int64_t tiles = (n + brief_wg_samples(nt) - 1) / brief_wg_samples(nt);
+    const int64_t wgs_ = fused_wg_samples(d, train);
+    const int64_t tiles = (n + wgs_ - 1) / wgs_;
     // resident workgroups per CU = what the kernel's launch bounds were compiled for (BRIEF_WG_PER_CU: diagnostics)
     const int wpe = g_wg_per_cu_set ? g_wg_per_cu : (train ? (d.precision == BRIEF_PREC_BF16X3 ? BRIEF_X3_WPE : fused_train_wpe(nt)) : (d.precision == BRIEF_PREC_BF16X3 && g_x3_decode ? BRIEF_X3_FWD_WPE : (nt > 8 ? 2 : 3)));
     const int64_t cap = (int64_t)kCUs * (train && nt > 8 ? 1 : wpe);      // TRAIN > 8 tiles: 512-register kernel, one workgroup per CU
@@ -2392,7 +2889,8 @@ static const int g_tail_rounds = env_int("BRIEF_TAIL_ROUNDS", 0, 0, 64);
 static FusedPlan fused_plan(const brief_siren_desc &d, int64_t n, bool train)
 {
     const int nt = brief_nt(d);
-    const int64_t tiles = (n + brief_wg_samples(nt) - 1) / brief_wg_samples(nt);
+    const int64_t wgs_ = fused_wg_samples(d, train);
+    const int64_t tiles = (n + wgs_ - 1) / wgs_;
     const int cap = fused_grid(d, n, train);
     FusedPlan p;
     p.grid = cap; p.pers_wgs = cap; p.pers_tiles = tiles;
@@ -2412,7 +2910,7 @@ static int wgrad_splits(const brief_siren_desc &d, int64_t n)
 {
     const int hidden = d.layers - 2;
     if (hidden <= 0) return 0;
-    const int64_t nchunks = brief_npad(brief_nt(d), n) / 32;
+    const int64_t nchunks = brief_npad_d(d, n) / 32;
     int64_t s = kWgradBlocks / (hidden * wgrad_nq(brief_nt(d)) * wgrad_nq(brief_nt(d)));
     if (s < 1) s = 1;
     if (s > nchunks) s = nchunks;
@@ -2498,7 +2996,7 @@ static WsLayout ws_layout(const brief_siren_desc &d, int64_t n)
         return w;
     }
     const int nt = brief_nt(d);
-    const int64_t FP = 32 * nt, npad = brief_npad(nt, n), hidden = d.layers - 2 > 0 ? d.layers - 2 : 0;
+    const int64_t FP = 32 * nt, npad = brief_npad_d(d, n), hidden = d.layers - 2 > 0 ? d.layers - 2 : 0;
     const bool small = use_small(d);
     WsLayout w;
     w.z = 0;
@@ -2554,6 +3052,17 @@ template <bool TRAIN>
 static int launch_fused(const FusedArgs &fa, int grid, hipStream_t st)
 {
     const int nt = brief_nt(fa.d);
+    if (TRAIN && fa.d.precision == BRIEF_PREC_BF16X3 && g_x3_t64) {
+        const size_t lds = sizeof(float) * X3TLds::TOTAL;
+        static bool attr_t64 = false;
+        if (!attr_t64) {
+            HIP_TRY(hipFuncSetAttribute((const void *)k_fused_x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_t64 = true;
+        }
+        hipLaunchKernelGGL(k_fused_x3, dim3(grid), dim3(256), lds, st, fa);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     if (fa.d.precision == BRIEF_PREC_BF16X3 && (TRAIN || g_x3_decode)) {
         // split-precision hidden GEMMs (FP = 256): the f32 kernel's skeleton with x3_chain / x3_write_image, + 2 KB of head partials.
         // Inference (forward / decode_grid) runs the same forward chains on fp16 halves: yhat within ~2e-6 of max|y| of the f32
@@ -2699,7 +3208,7 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
     if (!packed || !grads || !loss_out || !workspace) return fail(BRIEF_ERR_INVALID, "null buffer");
     if (loss_kind < BRIEF_LOSS_L2 || loss_kind > BRIEF_LOSS_EXTERNAL) return fail(BRIEF_ERR_INVALID, "bad loss_kind");
     if (d->precision == BRIEF_PREC_BF16 ? (int64_t)32 * brief_nt(*d) * npad16(batch->n) * 2 >= ((int64_t)1 << 31)
-                                       : (int64_t)32 * brief_nt(*d) * brief_npad(brief_nt(*d), batch->n) * 4 >= ((int64_t)1 << 31))
+                                       : (int64_t)32 * brief_nt(*d) * brief_npad_d(*d, batch->n) * 4 >= ((int64_t)1 << 31))
         return fail(BRIEF_ERR_INVALID, "batch too large for one train step (padded width x samples x 4 bytes must stay below 2 GiB): split it");
     const WsLayout wl = ws_layout(*d, batch->n);
     if (workspace_bytes < wl.total * (int64_t)sizeof(float)) return fail(BRIEF_ERR_WORKSPACE, "workspace too small");
@@ -2786,7 +3295,7 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
     if (!batch->idx && batch->rng_pop > 0) { fa.rng_pop = (uint64_t)batch->rng_pop; fa.rng_seed = batch->rng_seed; fa.rng_step = batch->rng_step; }
     fill_grid(fa.grid, grid);
     fa.loss_kind = loss_kind; fa.thr = thr; fa.beta = beta; fa.inv_count = inv_count;
-    fa.Z = ws + wl.z; fa.D = ws + wl.dd; fa.npad = brief_npad(nt, batch->n);
+    fa.Z = ws + wl.z; fa.D = ws + wl.dd; fa.npad = brief_npad_d(*d, batch->n);
     fa.rec = ws + wl.rec; fa.slabs = ws + wl.slabs; fa.yhat_out = yhat_out;
     fa.stagger_cus = kCUs; fa.stagger = g_stagger; fa.diag = g_diag;
     fa.pers_wgs = fp.pers_wgs; fa.pers_tiles = fp.pers_tiles;

@@ -123,3 +123,5 @@ BL_HD int64_t brief_npad(int nt, int64_t n)
     const int64_t g = brief_wg_samples(nt);
     return (n + g - 1) / g * g;
 }
+// padded sample count of the TRAIN stash planes
+BL_HD int64_t brief_npad_d(const brief_siren_desc &d, int64_t n) { return brief_npad(brief_nt(d), n); }
