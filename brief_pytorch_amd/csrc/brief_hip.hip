@@ -1342,14 +1342,13 @@ __global__ __launch_bounds__(256, 2) void k_fused_x3(const FusedArgs a)
             }
         }
         STAMP(5)
-        // ---- head gradients, one half after the other: transpose own h tiles through LDS (the scratch aliases the images: every
-        //      wave is past its last chain — the barrier above), lane <-> local feature
+        // ---- head gradients, one half after the other, from the transposed h this wave parked in its scratch (lane <-> local feature)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            if (h == 1 && !two) continue;      // (workgroup-uniform: the barriers below are skipped by every wave)
-            if (h) lds_barrier();      // the previous half's sums are done with G
+            if (h == 1 && !two) continue;
+            // (no barriers here: the transposed scratch and G are this wave's own, LDS operations of one wave execute in order)
             if (hi == 0) *reinterpret_cast<float4 *>(Gw + ln * 4) = make_float4(g[h][0], g[h][1], g[h][2], g[h][3]);
-            lds_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             {
                 float4 sW = make_float4(0.f, 0.f, 0.f, 0.f), sb = make_float4(0.f, 0.f, 0.f, 0.f);
                 const float *trow = T + (wave * 2 + h) * (K::TROWS * 33) + lane * 33;
@@ -1439,20 +1438,23 @@ __global__ __launch_bounds__(256, 2) void k_fused_x3(const FusedArgs a)
             x3_chain2<false>(acc, x3pre, rs_x3, (l - 1) * FP * FP * 4 + FP * FP * 2, x3_lo_bytes, X16, wm, lane, kit16, two);
             __builtin_amdgcn_s_setprio(0);
             STAMP(9)
-            // delta_{l-1} = acc * cos(phase_{l-1}): the phases come back from the stash after the chain (the SIMD's other wave covers it)
+            // delta_{l-1} = acc * cos(phase_{l-1}): the phases come back from the stash after the chain, a half (32 requests) at a time
+            // (all 64 at once: 152 B of scratch; a feature tile at a time: four exposed round trips per layer)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 if (h == 1 && !two) continue;
+                float zr[2][16];
                 const int voff_s = (int)(((ht + h) * 32) * (FP * 4)) + ln * 4 + hi * 4 * 128;
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const int mt = wm + 4 * t;
-                    float zr[16];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) zr[r] = bload1(rzp, voff_s, (32 * mt + (r & 3) + 8 * (r >> 2)) * 128);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[h][t][r] *= BRIEF_COS_REV(zr[r]);
+                    for (int r = 0; r < 16; ++r) zr[t][r] = bload1(rzp, voff_s, (32 * mt + (r & 3) + 8 * (r >> 2)) * 128);
                 }
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[h][t][r] *= BRIEF_COS_REV(zr[t][r]);
             }
         }
         STAMP(7)
@@ -1460,15 +1462,16 @@ __global__ __launch_bounds__(256, 2) void k_fused_x3(const FusedArgs a)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if (h == 1 && !two) continue;
-            lds_barrier();
+            if (h == 0) lds_barrier();      // the scratch aliases the images: every wave must be past the last dgrad chain
+            float *Tf = Tw + h * (K::TROWS * 33);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) Tw[(32 * t + ROWMAP(r, hi)) * 33 + ln] = acc[h][t][r];
+                for (int r = 0; r < 16; ++r) Tf[(32 * t + ROWMAP(r, hi)) * 33 + ln] = acc[h][t][r];
             if (hi == 1) *reinterpret_cast<float4 *>(Gw + 128 + ln * 4) = make_float4(x0[h], x1[h], x2[h], 1.0f);
-            lds_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // own-wave scratch: ordering only
             float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float *trow = Tw + lane * 33;
+            const float *trow = Tf + lane * 33;
 #pragma unroll 4
             for (int s = 0; s < 32; ++s) {
                 const float dv = trow[s];
