@@ -1042,7 +1042,7 @@ struct X3TLds {
     static constexpr int TOTAL = PART_OFF + 2 * 4 * 32 * 4;
 };
 
-template <bool F16>
+template <bool F16, bool BPRE>      // BPRE: B fragments a step ahead (16 more registers: the inference kernel has them)
 __device__ __forceinline__ void x3_chain2(f32x16 (&acc)[2][2], const X3Pre<8> &pre, __amdgpu_buffer_rsrc_t rs, int soff_layer, int lo_bytes,
                                           const uint4 *X16, int wm, int lane, int kit, bool two)
 {
@@ -1074,11 +1074,12 @@ __device__ __forceinline__ void x3_chain2(f32x16 (&acc)[2][2], const X3Pre<8> &p
         }
         // (B fragments are read in the step that uses them: a step ahead they cost 16 more registers, and with those the persistent
         //  per-tile state no longer fits beside the chain — 25 spilled dwords, reloaded from scratch in every head / gradient phase)
-        if (it > 0) {
+        if (BPRE ? it + 1 < NIT : it > 0) {
+            constexpr int ahead = BPRE ? 1 : 0;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                bhi[it][h] = X16[h * HALF + it * 64 + lane];
-                blo[it][h] = X16[h * HALF + NT * 2 * 64 + it * 64 + lane];
+                bhi[it + ahead][h] = X16[h * HALF + (it + ahead) * 64 + lane];
+                blo[it + ahead][h] = X16[h * HALF + NT * 2 * 64 + (it + ahead) * 64 + lane];
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1107,6 +1108,7 @@ __device__ __forceinline__ void x3_chain2(f32x16 (&acc)[2][2], const X3Pre<8> &p
     }
 }
 
+template <bool TRAIN>      // false: inference (forward / decode_grid) — the forward half of the same walk, output written by the head
 __global__ __launch_bounds__(256, 2) void k_fused_x3(const FusedArgs a)
 {
 #ifdef BRIEF_STAMPS
@@ -1240,7 +1242,7 @@ __global__ __launch_bounds__(256, 2) void k_fused_x3(const FusedArgs a)
                             acc[h][t][4 * q + 2] = BRIEF_X3_FWD_SCALE * bnext[t][q].z; acc[h][t][4 * q + 3] = BRIEF_X3_FWD_SCALE * bnext[t][q].w;
                         }
                 __builtin_amdgcn_s_setprio(3);
-                x3_chain2<true>(acc, x3pre, rs_x3, (l - 1) * FP * FP * 4, x3_lo_bytes, X16, wm, lane, kit16, two);
+                x3_chain2<true, !TRAIN>(acc, x3pre, rs_x3, (l - 1) * FP * FP * 4, x3_lo_bytes, X16, wm, lane, kit16, two);
                 __builtin_amdgcn_s_setprio(0);
                 STAMP(1)
                 lds_barrier();   // every wave is done reading the previous images
@@ -1264,10 +1266,12 @@ __global__ __launch_bounds__(256, 2) void k_fused_x3(const FusedArgs a)
                     for (int r = 0; r < 16; ++r) acc[h][t][r] = __builtin_amdgcn_fractf(l > 0 ? acc[h][t][r] * BRIEF_X3_FWD_UNSCALE : acc[h][t][r]);
                     f32x16 hv;
                     if (!last) {
+                        if (TRAIN) {
                         const __amdgpu_buffer_rsrc_t rz =
                             __builtin_amdgcn_make_buffer_rsrc((void *)(a.Z + (int64_t)l * FP * npad), 0, stash_bytes, 0x00020000);
 #pragma unroll
                         for (int r = 0; r < 16; ++r) bstore1(acc[h][t][r], rz, voff, (32 * mt + (r & 3) + 8 * (r >> 2)) * 128);
+                        }
 #pragma unroll
                         for (int r = 0; r < 16; ++r) hv[r] = BRIEF_SIN_REV(acc[h][t][r]);
                         x3_write_tile<true>(X16 + h * HALF, hv, mt, lane);
@@ -1275,7 +1279,7 @@ __global__ __launch_bounds__(256, 2) void k_fused_x3(const FusedArgs a)
                         // last sine layer: h feeds the head (from registers) and goes to this wave's transposed scratch for the head
                         // gradients (the images are dead: every wave is past the last chain's barrier); cos(phase) replaces the phase
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) { hv[r] = BRIEF_SIN_REV(acc[h][t][r]); acc[h][t][r] = BRIEF_COS_REV(acc[h][t][r]); }
+                        for (int r = 0; r < 16; ++r) { hv[r] = BRIEF_SIN_REV(acc[h][t][r]); if (TRAIN) acc[h][t][r] = BRIEF_COS_REV(acc[h][t][r]); }
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
                             if (c < cout) {
@@ -1287,9 +1291,11 @@ __global__ __launch_bounds__(256, 2) void k_fused_x3(const FusedArgs a)
                                 }
                             }
                         }
-                        float *Th = T + (wave * 2 + h) * (K::TROWS * 33);
+                        if (TRAIN) {
+                            float *Th = T + (wave * 2 + h) * (K::TROWS * 33);
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) Th[(32 * t + ROWMAP(r, hi)) * 33 + ln] = hv[r];
+                            for (int r = 0; r < 16; ++r) Th[(32 * t + ROWMAP(r, hi)) * 33 + ln] = hv[r];
+                        }
                     }
                 }
                 if (last) {
@@ -1321,6 +1327,22 @@ __global__ __launch_bounds__(256, 2) void k_fused_x3(const FusedArgs a)
                     zo[h][c] = tt[c] + HW[4 * FP + c];
                     yh[h][c] = d.output_act ? brief_fast_sinf(d.w0_hidden * zo[h][c]) : zo[h][c];
                 }
+                if (!TRAIN) {
+                    if (c < cout && valid[h] && wm == 0 && hi == 0) {
+                        if (a.out_kind == BRIEF_OUT_F32) {
+                            reinterpret_cast<float *>(a.out)[n * cout + c] = yh[h][c];
+                        } else {
+                            // utils/io.py:136-147: separate roundings, truncating cast
+                            float t_ = __fsub_rn(yh[h][c], a.scale_min);
+                            t_ = __fdiv_rn(t_, a.den);
+                            t_ = fminf(fmaxf(t_, 0.f), 1.f);
+                            const float u_ = __fadd_rn(__fmul_rn(t_, a.span), a.vmin);
+                            if (a.out_kind == BRIEF_OUT_U16) reinterpret_cast<uint16_t *>(a.out)[n * cout + c] = (uint16_t)(int)u_;
+                            else reinterpret_cast<uint8_t *>(a.out)[n * cout + c] = (uint8_t)(int)u_;
+                        }
+                    }
+                    continue;
+                }
                 // ---- loss and dloss/dyhat (main.py:176-191)
                 if (c < cout && valid[h]) {
                     const float yvc = k_tg[jidx[h] * cout + c];
@@ -1342,6 +1364,7 @@ __global__ __launch_bounds__(256, 2) void k_fused_x3(const FusedArgs a)
             }
         }
         STAMP(5)
+        if (!TRAIN) continue;      // (the next tile's first LDS writes come after its own barriers; the partials were read above)
         // ---- head gradients, one half after the other, from the transposed h this wave parked in its scratch (lane <-> local feature)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -1435,7 +1458,7 @@ __global__ __launch_bounds__(256, 2) void k_fused_x3(const FusedArgs a)
                     for (int r = 0; r < 16; ++r) acc[h][t][r] = 0.f;
             STAMP(8)
             __builtin_amdgcn_s_setprio(3);
-            x3_chain2<false>(acc, x3pre, rs_x3, (l - 1) * FP * FP * 4 + FP * FP * 2, x3_lo_bytes, X16, wm, lane, kit16, two);
+            x3_chain2<false, false>(acc, x3pre, rs_x3, (l - 1) * FP * FP * 4 + FP * FP * 2, x3_lo_bytes, X16, wm, lane, kit16, two);
             __builtin_amdgcn_s_setprio(0);
             STAMP(9)
             // delta_{l-1} = acc * cos(phase_{l-1}): the phases come back from the stash after the chain, a half (32 requests) at a time
@@ -1485,6 +1508,7 @@ __global__ __launch_bounds__(256, 2) void k_fused_x3(const FusedArgs a)
         STAMP(6)
     }
 #undef X3T_LOAD_BIAS
+    if (!TRAIN) return;
     float *rec = a.rec + ((int64_t)blockIdx.x * 4 + wave) * BRIEF_REC_FLOATS;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -3055,14 +3079,14 @@ template <bool TRAIN>
 static int launch_fused(const FusedArgs &fa, int grid, hipStream_t st)
 {
     const int nt = brief_nt(fa.d);
-    if (TRAIN && fa.d.precision == BRIEF_PREC_BF16X3 && g_x3_t64) {
+    if (fa.d.precision == BRIEF_PREC_BF16X3 && g_x3_t64 && (TRAIN || g_x3_decode)) {
         const size_t lds = sizeof(float) * X3TLds::TOTAL;
         static bool attr_t64 = false;
         if (!attr_t64) {
-            HIP_TRY(hipFuncSetAttribute((const void *)k_fused_x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIP_TRY(hipFuncSetAttribute((const void *)k_fused_x3<TRAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr_t64 = true;
         }
-        hipLaunchKernelGGL(k_fused_x3, dim3(grid), dim3(256), lds, st, fa);
+        hipLaunchKernelGGL(k_fused_x3<TRAIN>, dim3(grid), dim3(256), lds, st, fa);
         HIP_TRY(hipGetLastError());
         return 0;
     }
