@@ -52,7 +52,7 @@ def fused_kernel_name(precision, F):
     if precision == "fp32":
         return "k_fused<%d,true>" % (F // 32)
     if precision == "bf16x3":
-        return "k_fused<8,true,2> (split-precision bf16 MFMA, 3 per product)"
+        return "k_fused_x3<true> (split precision: fp16 / bf16 halves, 3 MFMAs per product, 64-sample tiles)"
     return "k16<%d,true,1>" % (F // 32)
 LAYERS, FEATURES, W0, SAMPLE = 5, 256, 20.0, 100000      # BASELINE config 2 (the metric's shape); --config c3 = 8x512
 BLOCK = (512, 512, 512)
@@ -270,7 +270,7 @@ def timed_config(name, L, F, dims, sampler, n, precision, steps, tgt=None, seed=
     return {**dec, "workload": name, "layers": L, "features": F, "volume": list(dims), "samples_per_step": nb, "dtype": DTYPES[precision],
             "steps": steps, "ms_per_step": el * 1e3 / steps, "voxels_per_s": nb * steps / el,
             "step_tflops": train_f * nb / (el / steps) / 1e12, "step_frac": train_f * nb / (el / steps) / 1e12 / peak,
-            "kernel": "k_small" if small else {"fp32": "k_fused", "bf16x3": "k_fused<8,true,2>", "bf16": "k16 (body + tail launches)"}[precision],
+            "kernel": "k_small" if small else {"fp32": "k_fused", "bf16x3": "k_fused_x3<true>", "bf16": "k16 (body + tail launches)"}[precision],
             "kernel_ms": kms, "kernel_tflops": kflop / (kms * 1e-3) / 1e12, "kernel_frac": kflop / (kms * 1e-3) / 1e12 / peak, "peak_tflops": peak}
 
 
