@@ -292,7 +292,7 @@ def rate_point(F, tgt, vol, vmin, vmax, steps, seed=42):
             "psnr_db": psnr, "seconds": time.perf_counter() - t0}
 
 
-def encode_decode_wall(vol_host, steps):
+def encode_decode_wall(vol_host, steps, precision="fp32"):
     """SURVEY 8d's encode figure, measured: wall clock around NFGR.compress of the HOST-resident volume (preprocess, the
     reference's `_preprocessed` dump, loss-weight map, normalise, H2D, net init, `steps` optimizer steps, weight files +
     sideinfos.yaml) and around NFGR.decompress of the stored artefact (load, decode kernel, D2H, postprocess)."""
@@ -309,6 +309,7 @@ def encode_decode_wall(vol_host, steps):
         cf.Compress.param.filesize_ratio, cf.Compress.param.given_size = 0, 4.0 * pcount
         cf.Compress.max_steps, cf.Compress.checkpoints, cf.Compress.loss_log_freq = steps, "none", 10 ** 9
         cf.Compress.decompress = False
+        cf.Compress.precision = precision
         cf["_seed"] = 42
         Log = MyLogger(outputs_dir=work, project_name="e2e", time=False)
         torch.manual_seed(42)
@@ -518,8 +519,12 @@ def main():
                    rate_point(384, tgt, vol, vmin, vmax, steps_done)]
             extra["psnr_at_bitrate_sweep"] = pts
             # ---- encode / decode as wall clocks of the product path on the host-resident volume
-            enc, dec_w = encode_decode_wall(vol.cpu().numpy(), args.encode_steps if args.encode_steps > 0 else 2000)
+            vol_h = vol.cpu().numpy()
+            enc, dec_w = encode_decode_wall(vol_h, args.encode_steps if args.encode_steps > 0 else 2000)
             extra["encode"], extra["decode"] = enc, dec_w
+            # the same two wall clocks with Compress.precision: bf16x3 (same seed, same steps; never the metric)
+            enc3, dec3 = encode_decode_wall(vol_h, args.encode_steps if args.encode_steps > 0 else 2000, "bf16x3")
+            cfgs["c2_512cube_4x256_bf16x3"]["encode"], cfgs["c2_512cube_4x256_bf16x3"]["decode"] = enc3, dec3
 
     if rank == 0:
         # HBM traffic of the dominant kernel: PMC counters need rocprofv3, so this figure is NOT measured in this run; it is
