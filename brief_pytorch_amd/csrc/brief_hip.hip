@@ -43,9 +43,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // row of accumulator register r (0..15) inside a 32x32 tile, for lane half hi
 #define ROWMAP(r, hi) (((r) & 3) + 8 * ((r) >> 2) + 4 * (hi))
 
-template <int NT>
+template <int NT, bool INFER = false>      // INFER: the inference kernels' wave mapping (brief_layout.h: brief_wm / brief_wm_infer)
 struct KCfg {
-    static constexpr int WM = NT >= 3 ? 4 : NT;       // waves along the feature dimension
+    static constexpr int WM = INFER ? brief_wm_infer(NT) : brief_wm(NT);           // waves along the feature dimension
     static constexpr int WS = 4 / WM;                 // 32-sample tiles per workgroup
     static constexpr int MTW = (NT + WM - 1) / WM;    // feature tiles owned by one wave
     static constexpr bool EXACT = (NT % WM) == 0;
@@ -191,11 +191,11 @@ __device__ __forceinline__ void bstore1(float v, __amdgpu_buffer_rsrc_t rs, int 
 // A fragments stream from the packed weight buffer (L2 resident) PD (kt,q)-steps ahead of use.
 // kit: (k-tile, q) steps that hold real features, ceil(F / 8): the steps above it multiply zero weight columns with the
 // zero activations of the padding features, so skipping them changes nothing but the time (F = 22 runs 3 of its 4 steps)
-template <int NT>
-__device__ __forceinline__ void chain(f32x16 (&acc)[KCfg<NT>::MTW], __amdgpu_buffer_rsrc_t rs, int soff_layer /*bytes*/,
+template <int NT, bool INFER = false>
+__device__ __forceinline__ void chain(f32x16 (&acc)[(KCfg<NT, INFER>::MTW)], __amdgpu_buffer_rsrc_t rs, int soff_layer /*bytes*/,
                                       const float4 *Xs, int wm, int lane, int kit)
 {
-    using K = KCfg<NT>;
+    using K = KCfg<NT, INFER>;
     constexpr int NIT = NT * 4;
     constexpr int PD = NIT < 4 ? NIT : 4;
     const int voff = lane * 16;
@@ -243,10 +243,10 @@ __device__ __forceinline__ void chain(f32x16 (&acc)[KCfg<NT>::MTW], __amdgpu_buf
     }
 }
 
-template <int NT>
-__device__ __forceinline__ void write_image(float4 *Xs, const f32x16 (&h)[KCfg<NT>::MTW], int wm, int lane)
+template <int NT, bool INFER = false>
+__device__ __forceinline__ void write_image(float4 *Xs, const f32x16 (&h)[(KCfg<NT, INFER>::MTW)], int wm, int lane)
 {
-    using K = KCfg<NT>;
+    using K = KCfg<NT, INFER>;
 #pragma unroll
     for (int t = 0; t < K::MTW; ++t) {
         const int mt = wm + K::WM * t;
@@ -464,9 +464,9 @@ __device__ __forceinline__ int64_t philox_index(int64_t i, uint64_t pop, uint64_
 //   image  X : WS x NT x 1024            activation register image(s)
 //   scratch T: 4 waves x 32*MTW x 33      per-wave [feature][sample] transpose (aliases X: used only while
 //                                         no wave reads the image, see the barriers below)
-template <int NT>
+template <int NT, bool INFER = false>
 struct FusedLds {
-    using K = KCfg<NT>;
+    using K = KCfg<NT, INFER>;
     static constexpr int R_FLOATS = K::XS_FLOATS > K::T_FLOATS ? K::XS_FLOATS : K::T_FLOATS;
     static constexpr int G_OFF = R_FLOATS;
     static constexpr int HW_OFF = G_OFF + K::G_FLOATS;
@@ -514,8 +514,8 @@ __global__ __launch_bounds__(256, TRAIN ? (PREC == 2 ? BRIEF_X3_WPE : fused_trai
     long long st_last = clock64();
     const long long st_c0 = st_last, st_r0 = wall_clock64();      // shader cycles / 100 MHz reference: the clock the kernel ran at
 #endif
-    using K = KCfg<NT>;
-    using LD = FusedLds<NT>;
+    using K = KCfg<NT, !TRAIN>;
+    using LD = FusedLds<NT, !TRAIN>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float4 *X = reinterpret_cast<float4 *>(smem);
     float *T = smem;                       // aliases X
@@ -688,7 +688,7 @@ __global__ __launch_bounds__(256, TRAIN ? (PREC == 2 ? BRIEF_X3_WPE : fused_trai
                 // order, epilogues first, costs +0.5 %: tools/ab_lib.sh, profiles/r02_issue_model.md)
                 if (TRAIN) __builtin_amdgcn_s_setprio(3);
                 if constexpr (PREC == 2) x3_chain<NT, true>(acc, x3pre, rs_x3, (l - 1) * K::FP * K::FP * 4, x3_lo_bytes, X16, wm, lane, kit16);
-                else chain<NT>(acc, rs_pk, (int)(brief_pk_hidden(d, l) * 4), Xs, wm, lane, kit);
+                else chain<NT, !TRAIN>(acc, rs_pk, (int)(brief_pk_hidden(d, l) * 4), Xs, wm, lane, kit);
                 if (TRAIN) __builtin_amdgcn_s_setprio(0);
                 STAMP(1)
                 lds_barrier();   // every wave is done reading the previous image
@@ -733,7 +733,7 @@ __global__ __launch_bounds__(256, TRAIN ? (PREC == 2 ? BRIEF_X3_WPE : fused_trai
                 }
             }
             if constexpr (PREC == 2) x3_write_image<NT, true>(X16, hreg, wm, lane);
-            else write_image<NT>(Xs, hreg, wm, lane);
+            else write_image<NT, !TRAIN>(Xs, hreg, wm, lane);
             STAMP(3)
             lds_barrier();
             STAMP(4)
@@ -943,7 +943,7 @@ __global__ __launch_bounds__(256, TRAIN ? (PREC == 2 ? BRIEF_X3_WPE : fused_trai
             STAMP(7)
             lds_barrier();   // transpose scratch / previous chain finished with the image region
             if constexpr (PREC == 2) x3_write_image<NT, false>(X16, dl, wm, lane);
-            else write_image<NT>(Xs, dl, wm, lane);
+            else write_image<NT, !TRAIN>(Xs, dl, wm, lane);
             lds_barrier();
             STAMP(8)
 #pragma unroll
@@ -952,7 +952,7 @@ __global__ __launch_bounds__(256, TRAIN ? (PREC == 2 ? BRIEF_X3_WPE : fused_trai
                 for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
             __builtin_amdgcn_s_setprio(3);
             if constexpr (PREC == 2) x3_chain<NT, false>(acc, x3pre, rs_x3, (l - 1) * K::FP * K::FP * 4 + K::FP * K::FP * 2, x3_lo_bytes, X16, wm, lane, kit16);
-            else chain<NT>(acc, rs_pk, (int)((brief_pk_hidden(d, l) + K::FP * K::FP) * 4), Xs, wm, lane, kit);
+            else chain<NT, !TRAIN>(acc, rs_pk, (int)((brief_pk_hidden(d, l) + K::FP * K::FP) * 4), Xs, wm, lane, kit);
             __builtin_amdgcn_s_setprio(0);
             STAMP(9)
             if (!ZPRE) FUSED_LOAD_Z()
@@ -2896,7 +2896,7 @@ static const int g_reduce_sg_small = env_int("BRIEF_REDUCE_SG", 0, 0, 64);      
 // samples one workgroup tile covers: 32 per sample sub-tile; the split-precision TRAIN kernel walks 64-sample tiles
 static int64_t fused_wg_samples(const brief_siren_desc &d, bool train)
 {
-    (void)train;
+    if (!train && d.precision == BRIEF_PREC_F32) return 32 * (4 / brief_wm_infer(brief_nt(d)));      // KCfg<NT, true>
     return brief_wg_samples(brief_nt(d));      // (the split-precision TRAIN kernel deals 32-sample half-tiles too, and walks them in pairs)
 }
 static int fused_grid(const brief_siren_desc &d, int64_t n, bool train)
@@ -3106,7 +3106,7 @@ static int launch_fused(const FusedArgs &fa, int grid, hipStream_t st)
     }
 #define BRIEF_CASE(NTV)                                                                                  \
     case NTV: {                                                                                          \
-        const size_t lds = sizeof(float) * FusedLds<NTV>::TOTAL;                                         \
+        const size_t lds = sizeof(float) * FusedLds<NTV, !TRAIN>::TOTAL;                                 \
         hipLaunchKernelGGL((k_fused<NTV, TRAIN>), dim3(grid), dim3(256), lds, st, fa);                   \
         break;                                                                                           \
     }

@@ -115,8 +115,14 @@ BL_HD float brief_om_prev(const brief_siren_desc &d, int l) { return l - 1 == 0 
 BL_HD float brief_phase_scale(const brief_siren_desc &d, int l) { return (l == 0 ? d.w0_first : d.w0_hidden) * 0.15915494309189535f; }
 
 // --- fused-kernel geometry per NT (how the 4 waves of a workgroup split features x sample tiles)
-BL_HD int brief_wm(int nt) { return nt >= 3 ? 4 : nt; }          // waves along features
-BL_HD int brief_ws(int nt) { return 4 / brief_wm(nt); }          // sample tiles (of 32) per workgroup
+// Five and six feature tiles: two waves per sample tile x three tile slots each, two sample tiles per workgroup (with four waves x
+// two slots, 3 / 2 of the 8 slots were empty: 5x192 step 0.769 -> 0.701 ms, 5x160 0.598 -> 0.584); 7 tiles keep the 4 x 2 slots.
+BL_HD constexpr int brief_wm(int nt) { return nt == 5 || nt == 6 ? 2 : (nt >= 3 ? 4 : nt); }          // waves along features (TRAIN kernels, k_reduce)
+// ... in the inference kernels (no records for k_reduce to agree with): three tiles -> one wave per sample tile owns all three (no idle
+// fourth wave: 256^3 decode of a 4x96 net 11.1 -> 8.7 ms; the TRAIN kernel spills in that form); five tiles keep 4 x 2 (25.1 ms against
+// 27.1 ms for a 4x160 net); six as above (34.2 -> 29.9 ms)
+BL_HD constexpr int brief_wm_infer(int nt) { return nt == 3 ? 1 : (nt == 5 ? 4 : brief_wm(nt)); }
+BL_HD constexpr int brief_ws(int nt) { return 4 / brief_wm(nt); }          // sample tiles (of 32) per workgroup
 BL_HD int64_t brief_wg_samples(int nt) { return 32 * brief_ws(nt); }
 BL_HD int64_t brief_npad(int nt, int64_t n)
 {

@@ -4,7 +4,7 @@ import sys, time, torch
 sys.path.insert(0, '.')
 from brief_pytorch_amd.fit import Fitter
 from brief_pytorch_amd.networks import SIREN
-for L, F in ((5, 128), (5, 96), (5, 256)):
+for L, F in ((5, 128), (5, 96), (5, 160), (5, 192), (5, 224), (5, 256)):
     torch.manual_seed(0)
     m = SIREN(features=F, layers=L, w0=20).to('cuda')
     tv = torch.rand(256 ** 3, 1, device='cuda') * 100

@@ -2,7 +2,7 @@
 import sys, torch, time
 sys.path.insert(0, '.')
 from brief_pytorch_amd.networks import SIREN
-for (L, F) in ((5, 22), (5, 35), (7, 56), (3, 64), (5, 96), (5, 128), (5, 256)):
+for (L, F) in ((5, 22), (5, 35), (7, 56), (3, 64), (5, 96), (5, 128), (5, 160), (5, 192), (5, 224), (5, 256)):
     torch.manual_seed(0)
     m = SIREN(features=F, layers=L, w0=20).to('cuda')
     dims = (256, 256, 256)
