@@ -494,7 +494,10 @@ struct FusedLds {
 #ifndef BRIEF_LEAN
 #define BRIEF_LEAN 1
 #endif
-constexpr bool fused_lean(int NT) { return BRIEF_LEAN && NT == 8; }
+#ifndef BRIEF_LEAN7
+#define BRIEF_LEAN7 0      // 7: the 7-tile kernel in the lean three-workgroup form too (experiment: 168 VGPRs + 128 B of scratch)
+#endif
+constexpr bool fused_lean(int NT) { return BRIEF_LEAN && (NT == 8 || NT == BRIEF_LEAN7); }
 #ifndef BRIEF_X3_LEAN
 #define BRIEF_X3_LEAN 0      // the split-precision kernel (two workgroups per CU) keeps its bias / phase prefetches
 #endif
