@@ -376,65 +376,6 @@ __device__ __forceinline__ void x3_preload(X3Pre<NT> &pre, __amdgpu_buffer_rsrc_
     for (int it = 0; it < BRIEF_X3_PD; ++it) X3_LOAD_INTO(pre.hi[it], pre.lo[it], it)
 }
 
-// one layer's GEMM for the feature tiles this wave owns, three 16-bit MFMAs per (A, B) fragment pair (F16: fp16 halves, else bf16).
-// rs: descriptor over the hi | lo fragment regions; soff_layer: byte offset of the layer's forward (or backward) block in the hi
-// region; lo_bytes: distance to the same block in the lo region.  kit: k-steps (of 16 features) that hold real features.
-// pre: the first PD k-steps of A fragments (x3_preload with the same rs / soff_layer / lo_bytes).
-template <int NT, bool F16>
-__device__ __forceinline__ void x3_chain(f32x16 (&acc)[KCfg<NT>::MTW], const X3Pre<NT> &pre, __amdgpu_buffer_rsrc_t rs, int soff_layer, int lo_bytes,
-                                         const uint4 *X16, int wm, int lane, int kit)
-{
-    using K = KCfg<NT>;
-    constexpr int NIT = NT * 2;
-    constexpr int PD = BRIEF_X3_PD;      // k-steps of A fragments (hi + lo: 4 KB per step and wave) in flight
-    const int voff = lane * 16;
-    int soff_w = soff_layer + wm * (NT * 2 * 1024);
-    asm volatile("" : "+s"(soff_w));
-    int soff_lo = lo_bytes;
-    asm volatile("" : "+s"(soff_lo));
-    uint4 ahi[NIT][K::MTW], alo[NIT][K::MTW];
-    uint4 bhi[NIT], blo[NIT];
-    // The loads are NOT predicated on kit (the padded k-steps hold zero fragments and zero activations): behind a wave-uniform
-    // branch the compiler's s_waitcnt bookkeeping joins the two paths pessimistically and waits for vmcnt(0) — the fragments
-    // fetched PD steps ahead included — inside every k-step, which is a prefetch depth of one.  Only the MFMAs are skipped.
-#pragma unroll
-    for (int it = 0; it < PD; ++it)
-#pragma unroll
-        for (int t = 0; t < K::MTW; ++t) { ahi[it][t] = pre.hi[it][t]; alo[it][t] = pre.lo[it][t]; }
-    bhi[0] = X16[lane]; blo[0] = X16[NT * 2 * 64 + lane];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-#ifndef BRIEF_X3_NOLOAD      // diagnostic build: only the first PD k-steps of weight fragments are fetched (results are garbage)
-        if (it + PD < NIT) X3_LOAD_INTO(ahi[it + PD], alo[it + PD], it + PD)
-#endif
-        if (it + 1 < NIT) { bhi[it + 1] = X16[(it + 1) * 64 + lane]; blo[it + 1] = X16[NT * 2 * 64 + (it + 1) * 64 + lane]; }
-        __builtin_amdgcn_sched_barrier(0);
-        if (it < kit) {
-            X3Frag fbh, fbl;
-            fbh.u = bhi[it]; fbl.u = blo[it];
-#pragma unroll
-            for (int t = 0; t < K::MTW; ++t) {
-                if (K::EXACT || wm + K::WM * t < NT) {
-                    X3Frag fah, fal;
-#ifdef BRIEF_X3_NOLOAD
-                    fah.u = ahi[it % PD][t]; fal.u = alo[it % PD][t];
-#else
-                    fah.u = ahi[it][t]; fal.u = alo[it][t];
-#endif
-                    if (F16) {
-                        acc[t] = MFMA_X3F(fah.f, fbh.f, acc[t]);
-                        acc[t] = MFMA_X3F(fah.f, fbl.f, acc[t]);
-                        acc[t] = MFMA_X3F(fal.f, fbh.f, acc[t]);
-                    } else {
-                        acc[t] = MFMA_X3(fah.v, fbh.v, acc[t]);
-                        acc[t] = MFMA_X3(fah.v, fbl.v, acc[t]);
-                        acc[t] = MFMA_X3(fal.v, fbh.v, acc[t]);
-                    }
-                }
-            }
-        }
-    }
-}
 #undef X3_LOAD_INTO
 
 // ---------------------------------------------------------------------------------------------
@@ -498,19 +439,9 @@ struct FusedLds {
 #define BRIEF_LEAN7 0      // 7: the 7-tile kernel in the lean three-workgroup form too (experiment: 168 VGPRs + 128 B of scratch)
 #endif
 constexpr bool fused_lean(int NT) { return BRIEF_LEAN && (NT == 8 || NT == BRIEF_LEAN7); }
-#ifndef BRIEF_X3_LEAN
-#define BRIEF_X3_LEAN 0      // the split-precision kernel (two workgroups per CU) keeps its bias / phase prefetches
-#endif
-#ifndef BRIEF_X3_WPE
-#define BRIEF_X3_WPE 2
-#endif
-#ifndef BRIEF_X3_FWD_WPE
-#define BRIEF_X3_FWD_WPE 2      // resident workgroups per CU of the split-precision inference kernel (3: 168 VGPRs + 92 B of scratch, 3 % slower)
-#endif
-constexpr bool fused_lean_p(int NT, int PREC) { return PREC == 2 ? (bool)BRIEF_X3_LEAN : fused_lean(NT); }
 constexpr int fused_train_wpe(int NT) { return NT > 8 ? 1 : (NT <= 4 || fused_lean(NT) ? (BRIEF_TRAIN_WPE > 3 ? BRIEF_TRAIN_WPE : 3) : BRIEF_TRAIN_WPE); }
-template <int NT, bool TRAIN, int PREC = 0 /* 0: f32 MFMA; 2: BRIEF_PREC_BF16X3 hidden GEMMs (x3_chain) */>
-__global__ __launch_bounds__(256, TRAIN ? (PREC == 2 ? BRIEF_X3_WPE : fused_train_wpe(NT)) : (PREC == 2 ? BRIEF_X3_FWD_WPE : (NT > 8 ? 2 : 3))) void k_fused(const FusedArgs a)
+template <int NT, bool TRAIN>
+__global__ __launch_bounds__(256, TRAIN ? fused_train_wpe(NT) : (NT > 8 ? 2 : 3)) void k_fused(const FusedArgs a)
 {
 #ifdef BRIEF_STAMPS
     float st_acc[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -524,13 +455,6 @@ __global__ __launch_bounds__(256, TRAIN ? (PREC == 2 ? BRIEF_X3_WPE : fused_trai
     float *T = smem;                       // aliases X
     float *G = smem + LD::G_OFF;
     float *HW = smem + LD::HW_OFF;         // Whp[4][FP], bhp[4]
-    uint4 *X16 = reinterpret_cast<uint4 *>(smem);      // PREC == 2: the image as hi | lo bf16 fragments (same bytes as the f32 image)
-    float4 *PART = reinterpret_cast<float4 *>(smem + LD::TOTAL);      // PREC == 2: head partials [4 waves][32 samples] (launch adds 2 KB)
-    const int kit16 = (a.d.features + 15) >> 4;
-    const __amdgpu_buffer_rsrc_t rs_x3 = PREC == 2
-        ? __builtin_amdgcn_make_buffer_rsrc((void *)(a.pk + brief_pk16_off(a.d, 1)), 0, (int)(2 * brief_pk16_region(a.d) * 4), 0x00020000)
-        : __builtin_amdgcn_make_buffer_rsrc((void *)a.pk, 0, 16, 0x00020000);
-    const int x3_lo_bytes = (int)(brief_pk16_region(a.d) * 4);
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -635,7 +559,6 @@ __global__ __launch_bounds__(256, TRAIN ? (PREC == 2 ? BRIEF_X3_WPE : fused_trai
         f32x16 acc[K::MTW];
         f32x16 creg[K::MTW];   // w*cos(w z) of the last sine layer (TRAIN)
         f32x16 hreg[K::MTW];
-        X3Pre<PREC == 2 ? NT : 1> x3pre;      // PREC == 2: the next chain's first A fragments (see x3_preload)
         float4 bnext[K::MTW][4];   // next hidden layer's bias, fetched one epilogue ahead of its use
 #pragma unroll
         for (int t = 0; t < K::MTW; ++t) {
@@ -676,29 +599,25 @@ __global__ __launch_bounds__(256, TRAIN ? (PREC == 2 ? BRIEF_X3_WPE : fused_trai
         for (int l = 0; l <= L - 2; ++l) {
             const bool last = (l == L - 2);
             if (l > 0) {
-                if (TRAIN && fused_lean_p(NT, PREC)) FUSED_LOAD_BIAS(l)      // lean variant: no register set parked across the epilogue
+                if (TRAIN && fused_lean(NT)) FUSED_LOAD_BIAS(l)      // lean variant: no register set parked across the epilogue
 #pragma unroll
                 for (int t = 0; t < K::MTW; ++t) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        // (split precision: the forward weight halves carry 2^6, so does the bias the accumulator starts from)
-                        constexpr float bs = PREC == 2 ? BRIEF_X3_FWD_SCALE : 1.0f;
-                        acc[t][4 * q] = bs * bnext[t][q].x; acc[t][4 * q + 1] = bs * bnext[t][q].y;
-                        acc[t][4 * q + 2] = bs * bnext[t][q].z; acc[t][4 * q + 3] = bs * bnext[t][q].w;
+                        acc[t][4 * q] = bnext[t][q].x; acc[t][4 * q + 1] = bnext[t][q].y;
+                        acc[t][4 * q + 2] = bnext[t][q].z; acc[t][4 * q + 3] = bnext[t][q].w;
                     }
                 }
                 // matrix work first: the wave inside a chain outranks its SIMD mate's epilogue (-0.5 % step time; the opposite
                 // order, epilogues first, costs +0.5 %: tools/ab_lib.sh, profiles/r02_issue_model.md)
                 if (TRAIN) __builtin_amdgcn_s_setprio(3);
-                if constexpr (PREC == 2) x3_chain<NT, true>(acc, x3pre, rs_x3, (l - 1) * K::FP * K::FP * 4, x3_lo_bytes, X16, wm, lane, kit16);
-                else chain<NT, !TRAIN>(acc, rs_pk, (int)(brief_pk_hidden(d, l) * 4), Xs, wm, lane, kit);
+                chain<NT, !TRAIN>(acc, rs_pk, (int)(brief_pk_hidden(d, l) * 4), Xs, wm, lane, kit);
                 if (TRAIN) __builtin_amdgcn_s_setprio(0);
                 STAMP(1)
                 lds_barrier();   // every wave is done reading the previous image
                 STAMP(2)
             }
-            if constexpr (PREC == 2) { if (!last) x3_preload<NT>(x3pre, rs_x3, l * K::FP * K::FP * 4, x3_lo_bytes, wm, lane); }      // ahead of this epilogue's stash stores
-            if (!last && !(TRAIN && fused_lean_p(NT, PREC))) FUSED_LOAD_BIAS(l + 1)   // lands while this epilogue computes its sines
+            if (!last && !(TRAIN && fused_lean(NT))) FUSED_LOAD_BIAS(l + 1)   // lands while this epilogue computes its sines
             // epilogue: stash z, h = sin(om z) (+ c = om cos(om z) on the last sine layer)
 #pragma unroll
             for (int t = 0; t < K::MTW; ++t) {
@@ -708,8 +627,7 @@ __global__ __launch_bounds__(256, TRAIN ? (PREC == 2 ? BRIEF_X3_WPE : fused_trai
                     // is what sin and cos are taken of, here and (TRAIN) again from the stash by the dgrad chain (cos) and by
                     // k_wgrad (sin).  One VALU instruction per element where the exact two-term reduction took five.
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        acc[t][r] = __builtin_amdgcn_fractf(PREC == 2 && l > 0 ? acc[t][r] * BRIEF_X3_FWD_UNSCALE : acc[t][r]);
+                    for (int r = 0; r < 16; ++r) acc[t][r] = __builtin_amdgcn_fractf(acc[t][r]);
                     if (TRAIN && !last) {
                         const __amdgpu_buffer_rsrc_t rz =
                             __builtin_amdgcn_make_buffer_rsrc((void *)(a.Z + (int64_t)l * K::FP * npad), 0, stash_bytes, 0x00020000);
@@ -735,8 +653,7 @@ __global__ __launch_bounds__(256, TRAIN ? (PREC == 2 ? BRIEF_X3_WPE : fused_trai
                     }
                 }
             }
-            if constexpr (PREC == 2) x3_write_image<NT, true>(X16, hreg, wm, lane);
-            else write_image<NT, !TRAIN>(Xs, hreg, wm, lane);
+            write_image<NT, !TRAIN>(Xs, hreg, wm, lane);
             STAMP(3)
             lds_barrier();
             STAMP(4)
@@ -746,7 +663,7 @@ __global__ __launch_bounds__(256, TRAIN ? (PREC == 2 ? BRIEF_X3_WPE : fused_trai
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             zo[c] = 0.f; yh[c] = 0.f; g[c] = 0.f;
-            if (c < cout && PREC != 2) {
+            if (c < cout) {
                 float p = 0.f;
                 const float *wrow = HW + c * K::FP;
 #pragma unroll
@@ -762,45 +679,6 @@ __global__ __launch_bounds__(256, TRAIN ? (PREC == 2 ? BRIEF_X3_WPE : fused_trai
                 p += __shfl_xor(p, 32);
                 zo[c] = p + HW[4 * K::FP + c];
                 yh[c] = d.output_act ? brief_fast_sinf(d.w0_hidden * zo[c]) : zo[c];
-            }
-        }
-        if constexpr (PREC == 2) {
-            // the image holds bf16 halves: the head is taken from the exact f32 activations instead — every wave's partial dot
-            // product over the features it owns, summed over the four waves through LDS in wave order
-            float pp[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (c < cout) {
-#pragma unroll
-                    for (int t = 0; t < K::MTW; ++t) {
-                        const int mt = wm + K::WM * t;
-                        if (K::EXACT || mt < NT) {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const float4 wv = *reinterpret_cast<const float4 *>(HW + c * K::FP + 32 * mt + 8 * q + 4 * hi);
-                                pp[c] = __fmaf_rn(wv.x, hreg[t][4 * q], pp[c]); pp[c] = __fmaf_rn(wv.y, hreg[t][4 * q + 1], pp[c]);
-                                pp[c] = __fmaf_rn(wv.z, hreg[t][4 * q + 2], pp[c]); pp[c] = __fmaf_rn(wv.w, hreg[t][4 * q + 3], pp[c]);
-                            }
-                        }
-                    }
-                    pp[c] += __shfl_xor(pp[c], 32);
-                }
-            }
-            if (hi == 0) PART[wave * 32 + ln] = make_float4(pp[0], pp[1], pp[2], pp[3]);
-            lds_barrier();
-            float4 tot = PART[ws * K::WM * 32 + ln];
-#pragma unroll
-            for (int w = 1; w < K::WM; ++w) {
-                const float4 v = PART[(ws * K::WM + w) * 32 + ln];
-                tot.x += v.x; tot.y += v.y; tot.z += v.z; tot.w += v.w;
-            }
-            const float tt[4] = {tot.x, tot.y, tot.z, tot.w};
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (c < cout) {
-                    zo[c] = tt[c] + HW[4 * K::FP + c];
-                    yh[c] = d.output_act ? brief_fast_sinf(d.w0_hidden * zo[c]) : zo[c];
-                }
             }
         }
         if (!TRAIN) {
@@ -919,7 +797,6 @@ __global__ __launch_bounds__(256, TRAIN ? (PREC == 2 ? BRIEF_X3_WPE : fused_trai
             const __amdgpu_buffer_rsrc_t rd =
                 __builtin_amdgcn_make_buffer_rsrc((void *)(a.D + (int64_t)(l - 1) * K::FP * npad), 0, stash_bytes, 0x00020000);
             const int voff_s = (int)(n0 * (K::FP * 4)) + ln * 4 + hi * 4 * 128;
-            if constexpr (PREC == 2) x3_preload<NT>(x3pre, rs_x3, (l - 1) * K::FP * K::FP * 4 + K::FP * K::FP * 2, x3_lo_bytes, wm, lane);      // ahead of the delta stores and phase loads
 #pragma unroll
             for (int t = 0; t < K::MTW; ++t) {
                 const int mt = wm + K::WM * t;
@@ -933,7 +810,7 @@ __global__ __launch_bounds__(256, TRAIN ? (PREC == 2 ? BRIEF_X3_WPE : fused_trai
             const __amdgpu_buffer_rsrc_t rzp =
                 __builtin_amdgcn_make_buffer_rsrc((void *)(a.Z + (int64_t)(l - 1) * K::FP * npad), 0, stash_bytes, 0x00020000);
             float zr[K::MTW][16];
-            constexpr bool ZPRE = !fused_lean_p(NT, PREC);      // lean variant: the phases are fetched after the chain (two other waves cover the latency)
+            constexpr bool ZPRE = !fused_lean(NT);      // lean variant: the phases are fetched after the chain (two other waves cover the latency)
 #define FUSED_LOAD_Z()                                                                                  \
     _Pragma("unroll") for (int t = 0; t < K::MTW; ++t) {                                                \
         const int mt = wm + K::WM * t;                                                                  \
@@ -945,8 +822,7 @@ __global__ __launch_bounds__(256, TRAIN ? (PREC == 2 ? BRIEF_X3_WPE : fused_trai
             if (ZPRE) FUSED_LOAD_Z()
             STAMP(7)
             lds_barrier();   // transpose scratch / previous chain finished with the image region
-            if constexpr (PREC == 2) x3_write_image<NT, false>(X16, dl, wm, lane);
-            else write_image<NT, !TRAIN>(Xs, dl, wm, lane);
+            write_image<NT, !TRAIN>(Xs, dl, wm, lane);
             lds_barrier();
             STAMP(8)
 #pragma unroll
@@ -954,8 +830,7 @@ __global__ __launch_bounds__(256, TRAIN ? (PREC == 2 ? BRIEF_X3_WPE : fused_trai
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
             __builtin_amdgcn_s_setprio(3);
-            if constexpr (PREC == 2) x3_chain<NT, false>(acc, x3pre, rs_x3, (l - 1) * K::FP * K::FP * 4 + K::FP * K::FP * 2, x3_lo_bytes, X16, wm, lane, kit16);
-            else chain<NT, !TRAIN>(acc, rs_pk, (int)((brief_pk_hidden(d, l) + K::FP * K::FP) * 4), Xs, wm, lane, kit);
+            chain<NT, !TRAIN>(acc, rs_pk, (int)((brief_pk_hidden(d, l) + K::FP * K::FP) * 4), Xs, wm, lane, kit);
             __builtin_amdgcn_s_setprio(0);
             STAMP(9)
             if (!ZPRE) FUSED_LOAD_Z()
@@ -1029,11 +904,12 @@ __global__ __launch_bounds__(256, TRAIN ? (PREC == 2 ? BRIEF_X3_WPE : fused_trai
 }
 
 // ---------------------------------------------------------------------------------------------
-// BRIEF_PREC_BF16X3 train step, 64-sample tiles: k_fused<8,true,2>'s job with every A (weight) fragment used against TWO B
+// BRIEF_PREC_BF16X3 train step and inference, 64-sample tiles: k_fused<8>'s job on split-precision MFMAs, every A (weight) fragment against TWO B
 // fragments (two 32-sample halves of the tile).  A 32-sample tile pulls 256 KB of hi | lo fragments per layer through the CU's
 // 64 B/clk vector-memory path — 4 096 cycles per tile-layer against 3 072 cycles of MFMA issue, the chains of the 32-sample
 // kernel ran at 7.7 k cycles per layer; here a wave owns 2 feature tiles x 2 sample halves (64 accumulator registers) and the
-// same bytes feed twice the MFMAs.  Same arithmetic per sample as k_fused<8,true,2> (fp16 halves forward, bf16 halves
+// same bytes feed twice the MFMAs (a 32-sample form of this kernel lived inside k_fused until the end of round 3: git history,
+// profiles/r03_bf16x3.md).  fp16 halves forward, bf16 halves
 // backward, f32 stashes in the same tile-blocked planes, same records for k_reduce); only the order in which a workgroup's
 // samples enter its skinny-gradient sums differs.  LDS: two hi | lo images (64 KB) + G + head weights + head partials = 76 KB,
 // two workgroups per CU.
@@ -2891,7 +2767,6 @@ static const int g_wg_per_cu = env_int("BRIEF_WG_PER_CU", BRIEF_TRAIN_WPE, 1, 4)
 static const bool g_wg_per_cu_set = getenv("BRIEF_WG_PER_CU") != nullptr;
 static const int g_stagger = env_int("BRIEF_STAGGER", 0, 0, 64);      // start delay per residency slot: measured neutral with two and with three workgroups per CU (profiles/r03_wg_timeline.md), off
 static const int g_diag = env_int("BRIEF_DIAG", 0, 0, 255);
-static const int g_x3_t64 = env_int("BRIEF_X3_T64", 1, 0, 1);            // 0 (diagnostics): BRIEF_PREC_BF16X3 trains on the 32-sample kernel (k_fused<8,true,2>) instead of k_fused_x3
 static const int g_x3_decode = env_int("BRIEF_X3_DECODE", 1, 0, 1);      // 0 (diagnostics): BRIEF_PREC_BF16X3 nets are evaluated by the f32 forward kernel
 static const int g_wgrad_repeat = env_int("BRIEF_WGRAD_REPEAT", 1, 1, 8);      // diagnostics: k_wgrad_x3 launched this many times per step (reads of data that k_fused has just written vs data at rest)
 static const int g_reduce_sg_big = env_int("BRIEF_REDUCE_SG_BIG", 4, 1, 64);
@@ -2908,7 +2783,7 @@ static int fused_grid(const brief_siren_desc &d, int64_t n, bool train)
     const int64_t wgs_ = fused_wg_samples(d, train);
     const int64_t tiles = (n + wgs_ - 1) / wgs_;
     // resident workgroups per CU = what the kernel's launch bounds were compiled for (BRIEF_WG_PER_CU: diagnostics)
-    const int wpe = g_wg_per_cu_set ? g_wg_per_cu : (train ? (d.precision == BRIEF_PREC_BF16X3 ? BRIEF_X3_WPE : fused_train_wpe(nt)) : (d.precision == BRIEF_PREC_BF16X3 && g_x3_decode ? BRIEF_X3_FWD_WPE : (nt > 8 ? 2 : 3)));
+    const int wpe = g_wg_per_cu_set ? g_wg_per_cu : (d.precision == BRIEF_PREC_BF16X3 && (train || g_x3_decode) ? 2 /* k_fused_x3 */ : (train ? fused_train_wpe(nt) : (nt > 8 ? 2 : 3)));
     const int64_t cap = (int64_t)kCUs * (train && nt > 8 ? 1 : wpe);      // TRAIN > 8 tiles: 512-register kernel, one workgroup per CU
     return (int)(tiles < cap ? (tiles > 0 ? tiles : 1) : cap);
 }
@@ -3082,7 +2957,8 @@ template <bool TRAIN>
 static int launch_fused(const FusedArgs &fa, int grid, hipStream_t st)
 {
     const int nt = brief_nt(fa.d);
-    if (fa.d.precision == BRIEF_PREC_BF16X3 && g_x3_t64 && (TRAIN || g_x3_decode)) {
+    if (fa.d.precision == BRIEF_PREC_BF16X3 && (TRAIN || g_x3_decode)) {
+        // split precision: the 64-sample walk (k_fused_x3); BRIEF_X3_DECODE=0 evaluates such a net on the f32 forward kernel below
         const size_t lds = sizeof(float) * X3TLds::TOTAL;
         static bool attr_t64 = false;
         if (!attr_t64) {
@@ -3090,20 +2966,6 @@ static int launch_fused(const FusedArgs &fa, int grid, hipStream_t st)
             attr_t64 = true;
         }
         hipLaunchKernelGGL(k_fused_x3<TRAIN>, dim3(grid), dim3(256), lds, st, fa);
-        HIP_TRY(hipGetLastError());
-        return 0;
-    }
-    if (fa.d.precision == BRIEF_PREC_BF16X3 && (TRAIN || g_x3_decode)) {
-        // split-precision hidden GEMMs (FP = 256): the f32 kernel's skeleton with x3_chain / x3_write_image, + 2 KB of head partials.
-        // Inference (forward / decode_grid) runs the same forward chains on fp16 halves: yhat within ~2e-6 of max|y| of the f32
-        // kernel's (BRIEF_X3_DECODE=0: the f32 kernel instead, diagnostics)
-        const size_t lds = sizeof(float) * FusedLds<8>::TOTAL + 4 * 32 * sizeof(float4);
-        static bool attr_x3 = false;
-        if (!attr_x3) {
-            HIP_TRY(hipFuncSetAttribute((const void *)k_fused<8, TRAIN, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_x3 = true;
-        }
-        hipLaunchKernelGGL((k_fused<8, TRAIN, 2>), dim3(grid), dim3(256), lds, st, fa);
         HIP_TRY(hipGetLastError());
         return 0;
     }
