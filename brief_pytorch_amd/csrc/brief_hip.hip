@@ -178,6 +178,14 @@ __device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t rs, int voff, in
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
+#ifndef BRIEF_WGRAD_AUX
+#define BRIEF_WGRAD_AUX 0      // cache policy of k_wgrad's operand panels (2: streaming)
+#endif
+__device__ __forceinline__ float4 bload4w(__amdgpu_buffer_rsrc_t rs, int voff, int soff)
+{
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, BRIEF_WGRAD_AUX);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
 __device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t rs, int voff, int soff)
 {
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
@@ -185,6 +193,18 @@ __device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t rs, int voff, int
 __device__ __forceinline__ void bstore1(float v, __amdgpu_buffer_rsrc_t rs, int voff, int soff)
 {
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, voff, soff, 0);
+}
+// the split-precision fused kernel's stash accesses, with a cache-policy knob of their own (see BRIEF_X3W_AUX for the reader's side)
+#ifndef BRIEF_X3_STASH_AUX
+#define BRIEF_X3_STASH_AUX 0      // k_fused_x3's own stash stores / phase reloads: the streaming policy costs it 9-10 us (measured), default policy
+#endif
+__device__ __forceinline__ float bload1s(__amdgpu_buffer_rsrc_t rs, int voff, int soff)
+{
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, BRIEF_X3_STASH_AUX));
+}
+__device__ __forceinline__ void bstore1s(float v, __amdgpu_buffer_rsrc_t rs, int voff, int soff)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, voff, soff, BRIEF_X3_STASH_AUX);
 }
 
 // One layer's GEMM for the feature tiles this wave owns:  acc[t] += A(mt,:) * image.
@@ -1149,7 +1169,7 @@ __global__ __launch_bounds__(256, 2) void k_fused_x3(const FusedArgs a)
                         const __amdgpu_buffer_rsrc_t rz =
                             __builtin_amdgcn_make_buffer_rsrc((void *)(a.Z + (int64_t)l * FP * npad), 0, stash_bytes, 0x00020000);
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) bstore1(acc[h][t][r], rz, voff, (32 * mt + (r & 3) + 8 * (r >> 2)) * 128);
+                        for (int r = 0; r < 16; ++r) bstore1s(acc[h][t][r], rz, voff, (32 * mt + (r & 3) + 8 * (r >> 2)) * 128);
                         }
 #pragma unroll
                         for (int r = 0; r < 16; ++r) hv[r] = BRIEF_SIN_REV(acc[h][t][r]);
@@ -1320,7 +1340,7 @@ __global__ __launch_bounds__(256, 2) void k_fused_x3(const FusedArgs a)
                 for (int t = 0; t < 2; ++t) {
                     const int mt = wm + 4 * t;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) bstore1(acc[h][t][r], rd, voff_s, (32 * mt + (r & 3) + 8 * (r >> 2)) * 128);
+                    for (int r = 0; r < 16; ++r) bstore1s(acc[h][t][r], rd, voff_s, (32 * mt + (r & 3) + 8 * (r >> 2)) * 128);
                 }
             }
             STAMP(7)
@@ -1351,7 +1371,7 @@ __global__ __launch_bounds__(256, 2) void k_fused_x3(const FusedArgs a)
                 for (int t = 0; t < 2; ++t) {
                     const int mt = wm + 4 * t;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) zr[t][r] = bload1(rzp, voff_s, (32 * mt + (r & 3) + 8 * (r >> 2)) * 128);
+                    for (int r = 0; r < 16; ++r) zr[t][r] = bload1s(rzp, voff_s, (32 * mt + (r & 3) + 8 * (r >> 2)) * 128);
                 }
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
@@ -1927,8 +1947,8 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
         ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);                                                  \
         rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);                                                  \
         if (FULL || e < QP * 8) {                                                                 \
-            ra[i] = bload4(rsD, voffs[i], (int)((cc) * (FP * 128)));                                     \
-            rb[i] = bload4(rsZ, voffs[i], (int)((cc) * (FP * 128)));                                     \
+            ra[i] = bload4w(rsD, voffs[i], (int)((cc) * (FP * 128)));                                    \
+            rb[i] = bload4w(rsZ, voffs[i], (int)((cc) * (FP * 128)));                                    \
         }                                                                                         \
     }
 #define WG_STAGE_A(buf, i)                                                                        \
@@ -2120,7 +2140,10 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_x3(const WgradArgs a)
         voffs[i] = e * 16;
     }
 #define X3F(u_) __uint_as_float(u_)
-#define X3W_LD(rs_, base_, voff_, soff_) __builtin_amdgcn_raw_buffer_load_b128(rs_, voff_, soff_, 0)
+#ifndef BRIEF_X3W_AUX
+#define BRIEF_X3W_AUX 2      // streaming cache policy for the operand panels: read once (aux 0: 155 us, aux 2: 115 us)
+#endif
+#define X3W_LD(rs_, base_, voff_, soff_) __builtin_amdgcn_raw_buffer_load_b128(rs_, voff_, soff_, BRIEF_X3W_AUX)
 #define X3W_ISSUE(cc)                                                                             \
     _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                             \
         ra[i] = X3W_LD(rsD, Dl, voffs[i], (int)((cc) * (FP * 128)));       \
