@@ -195,12 +195,15 @@ __device__ __forceinline__ void bstore1(float v, __amdgpu_buffer_rsrc_t rs, int 
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, voff, soff, 0);
 }
 // the split-precision fused kernel's stash accesses, with a cache-policy knob of their own (see BRIEF_X3W_AUX for the reader's side)
+#ifndef BRIEF_STASH_LD_AUX
+#define BRIEF_STASH_LD_AUX 0      // phase reloads of the dgrad chains (k_fused and k_fused_x3): read once (experiment: 2)
+#endif
 #ifndef BRIEF_X3_STASH_AUX
 #define BRIEF_X3_STASH_AUX 0      // k_fused_x3's own stash stores / phase reloads: the streaming policy costs it 9-10 us (measured), default policy
 #endif
 __device__ __forceinline__ float bload1s(__amdgpu_buffer_rsrc_t rs, int voff, int soff)
 {
-    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, BRIEF_X3_STASH_AUX));
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, BRIEF_STASH_LD_AUX));
 }
 __device__ __forceinline__ void bstore1s(float v, __amdgpu_buffer_rsrc_t rs, int voff, int soff)
 {
@@ -836,7 +839,7 @@ __global__ __launch_bounds__(256, TRAIN ? fused_train_wpe(NT) : (NT > 8 ? 2 : 3)
         const int mt = wm + K::WM * t;                                                                  \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                \
             zr[t][r] = 0.f;                                                                             \
-            if (K::EXACT || mt < NT) zr[t][r] = bload1(rzp, voff_s, (32 * mt + (r & 3) + 8 * (r >> 2)) * 128); \
+            if (K::EXACT || mt < NT) zr[t][r] = bload1s(rzp, voff_s, (32 * mt + (r & 3) + 8 * (r >> 2)) * 128); \
         }                                                                                               \
     }
             if (ZPRE) FUSED_LOAD_Z()
