@@ -242,3 +242,28 @@ def test_singletask_bf16x3_option_matches_the_fp32_run(tmp_path):
             assert np.array_equal(again, read_img(os.path.join(sdir, "decompressed", "v_decompressed.tif")))
     print("150-step SingleTask fit: fp32 %.3f dB, bf16x3 %.3f dB" % (psnr["fp32"], psnr["bf16x3"]))
     assert psnr["fp32"] > 25 and abs(psnr["fp32"] - psnr["bf16x3"]) < 0.05
+
+
+def test_autograd_route_external_gradients():
+    """the reference-style loop (forward -> torch loss -> backward) on a bf16x3 module: autograd's dL/dyhat enters the fused backward as
+    BRIEF_LOSS_EXTERNAL; the parameter gradient agrees with the fp32 module's to the fp32 band (every tensor 1e-4 of its max-abs)"""
+    import torch.nn.functional as Fnn
+    grads = {}
+    dims = (12, 16, 20)
+    n = 12 * 16 * 20
+    y = (torch.rand(n, 1, generator=torch.Generator().manual_seed(1)) * 100).to(DEV)
+    lin = [torch.linspace(-1, 1, d) for d in dims]
+    x = torch.stack(torch.meshgrid(*lin, indexing="ij"), -1).reshape(1, *dims, 3).to(DEV)
+    for prec in ("fp32", "bf16x3"):
+        torch.manual_seed(7)
+        m = SIREN(features=200, layers=5, w0=20, precision=prec).to(DEV)
+        m.requires_grad_(True)
+        yhat = m.forward(x)
+        assert yhat.requires_grad
+        Fnn.mse_loss(yhat, y.view(1, *dims, 1)).backward()
+        grads[prec] = m.params.grad.detach().cpu().numpy().copy()
+        d = O.make_desc(3, 1, 5, 200, 20.0)
+    a, b = O.unpack_params(d, grads["bf16x3"]), O.unpack_params(d, grads["fp32"])
+    worst = max(max(relerr(a[0][k], b[0][k]), relerr(a[1][k], b[1][k])) for k in range(5))
+    print("autograd route: worst gradient tensor, bf16x3 against fp32: %.2e" % worst)
+    assert worst < 1e-4
