@@ -267,3 +267,42 @@ def test_autograd_route_external_gradients():
     worst = max(max(relerr(a[0][k], b[0][k]), relerr(a[1][k], b[1][k])) for k in range(5))
     print("autograd route: worst gradient tensor, bf16x3 against fp32: %.2e" % worst)
     assert worst < 1e-4
+
+
+def test_dividetask_bf16x3_blocks(tmp_path):
+    """Compress.precision: bf16x3 through NFGR.compress_divide: four 16x16x16 blocks with ~150-wide nets co-trained by brief_multi_fit,
+    the merged volume rebuilt from the stored artefact tree bit for bit, PSNR where the fp32 run of the same seed lands"""
+    from brief_pytorch_amd import config, misc
+    from brief_pytorch_amd.framework import NFGR, MyLogger
+    from brief_pytorch_amd.synthetic import make_volume
+    from brief_pytorch_amd.tool import read_img, save_img
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    vol = make_volume((16, 32, 32), seed=3)
+    path = str(tmp_path / "blk.tif")
+    save_img(path, vol)
+    psnr = {}
+    for prec in ("fp32", "bf16x3"):
+        opt = config.load(os.path.join(root, "opt", "SingleTask", "default.yaml"))
+        cf = opt.CompressFramework
+        cf.Compress.max_steps, cf.Compress.checkpoints, cf.Compress.loss_log_freq = 150, "none", 50
+        cf.Compress.param.filesize_ratio, cf.Compress.param.given_size = 0, 4 * 4.0 * SIREN.calc_param_count(3, 1, 150, 4)
+        cf.Compress.divide.divide_type, cf.Compress.divide.param_alloc = "total_1_2_2", "by_size"
+        cf.Module.phi.layers = 4
+        cf.Compress.precision = prec
+        opt.Log.outputs_dir, opt.Log.time = str(tmp_path / ("outputs_" + prec)), False
+        Log = MyLogger(**opt.Log)
+        torch.manual_seed(42)
+        fw = NFGR(cf, Log=Log)
+        res = fw.compress_divide(path, opt)
+        psnr[prec] = res[150]["psnr"]
+        if prec == "bf16x3":
+            cdir = os.path.join(Log.logdir, "steps150", "compressed")
+            names = sorted(os.listdir(os.path.join(cdir, "module")))
+            assert names == sorted(c["name"] for c in misc.divide_data(vol, "total_1_2_2")[0])
+            side = config.load(os.path.join(cdir, "sideinfos", names[0], "sideinfos.yaml"))
+            assert side["phi_precision"] == "bf16x3" and 128 < side["phi_features"] <= 256
+            merged = read_img(os.path.join(Log.logdir, "steps150", "decompressed", "blk_decompressed.tif"))
+            again = fw.decompress_divide(os.path.join(cdir, "sideinfos.yaml"), os.path.join(cdir, "module"), os.path.join(cdir, "sideinfos"))
+            assert np.array_equal(again, merged)
+    print("DivideTask 150 steps: fp32 %.3f dB, bf16x3 %.3f dB" % (psnr["fp32"], psnr["bf16x3"]))
+    assert psnr["fp32"] > 24 and abs(psnr["fp32"] - psnr["bf16x3"]) < 0.1
