@@ -1081,22 +1081,31 @@ __global__ __launch_bounds__(256, 2) void k_fused_x3(const FusedArgs a)
         int64_t jidx[2];      // targets and loss weights are fetched at the loss (two workgroups per CU cover the latency; 16 registers less across the forward pass)
         bool valid[2];
         f32x16 acc[2][2];      // ONE 64-register array per wave: accumulators -> phases -> cos of the last layer -> deltas (in place throughout)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int64_t n = (ht + h) * 32 + ln;
-            valid[h] = (h == 0 || two) && n < a.n;
+        // The 64 lanes draw the pair's 64 sample indices and coordinates ONCE (lane = sample: lanes 0..31 the first half, 32..63 the
+        // second) and then hand every lane both halves' values for its column ln through the cross-lane network; computed per half as
+        // in k_fused, the Philox draw, the 64-bit modulo and the grid coordinates ran twice (6 % of the kernel for this phase).
+        {
+            const int64_t n64 = ht * 32 + lane;
+            const bool v64 = (lane < 32 || two) && n64 < a.n;
             int64_t j = 0;
-            if (valid[h]) j = k_idx ? k_idx[n] : (k_pop ? philox_index(n, k_pop, k_seed, k_step) : n + k_off);
-            x0[h] = 0.f; x1[h] = 0.f; x2[h] = 0.f;
-            jidx[h] = j;
-            if (valid[h]) {
+            if (v64) j = k_idx ? k_idx[n64] : (k_pop ? philox_index(n64, k_pop, k_seed, k_step) : n64 + k_off);
+            float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+            if (v64) {
                 if (k_co) {
-                    x0[h] = k_co[j * cin];
-                    x1[h] = k_co[j * cin + 1];
-                    if (cin == 3) x2[h] = k_co[j * cin + 2];
+                    c0 = k_co[j * cin];
+                    c1 = k_co[j * cin + 1];
+                    if (cin == 3) c2 = k_co[j * cin + 2];
                 } else {
-                    grid_coords(kg, cin, j, x0[h], x1[h], x2[h]);
+                    grid_coords(kg, cin, j, c0, c1, c2);
                 }
+            }
+            const int jl = (int)(uint32_t)(uint64_t)j, jh = (int)(uint32_t)((uint64_t)j >> 32);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int src = 32 * h + ln;
+                x0[h] = __shfl(c0, src); x1[h] = __shfl(c1, src); x2[h] = __shfl(c2, src);
+                jidx[h] = (int64_t)(((uint64_t)(uint32_t)__shfl(jh, src) << 32) | (uint32_t)__shfl(jl, src));
+                valid[h] = (h == 0 || two) && (ht + h) * 32 + ln < a.n;
             }
         }
         X3Pre<8> x3pre;
