@@ -58,23 +58,35 @@ EXPORTS = ["brief_version", "brief_last_error", "brief_param_count", "brief_pack
 
 
 def needs_build():
+    if LIB_PATH != os.path.join(_HERE, "libbrief_hip.so"):
+        return False          # BRIEF_LIB names somebody else's build
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in _DEPS)
 
 
-def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -> brief_pytorch_amd/libbrief_hip.so (in-tree)."""
-    if not force and not needs_build():
+DIAG_LIB_PATH = os.path.join(_HERE, "libbrief_hip_diag.so")
+
+
+def build(force=False, verbose=False, diagnostics=False, defines=(), out=None):
+    """hipcc --offload-arch=gfx950 -> brief_pytorch_amd/libbrief_hip.so (in-tree).
+
+    diagnostics=True builds libbrief_hip_diag.so with -DBRIEF_DIAGNOSTICS instead: the only build that reads the
+    BRIEF_* environment knobs of tools/ (select it with BRIEF_LIB=...); the product library never calls getenv."""
+    target = out or (DIAG_LIB_PATH if diagnostics else os.path.join(_HERE, "libbrief_hip.so"))
+    if not force and not diagnostics and not defines and out is None and not needs_build():
         return LIB_PATH
     # -ffp-contract=off: every fused multiply-add in the kernels is an explicit fmaf/MFMA, so the
     # optimizer and de-normalise epilogues keep the separate roundings of the reference arithmetic
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", SRC, "-o", LIB_PATH]
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", SRC, "-o", target]
+    if diagnostics:
+        cmd.append("-DBRIEF_DIAGNOSTICS")
+    cmd += ["-D" + d for d in defines]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB_PATH
+    return target
 
 
 _LIB = None

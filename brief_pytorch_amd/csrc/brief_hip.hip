@@ -2788,18 +2788,24 @@ static OptimScalars optim_scalars(int kind, double lr, double beta1, double beta
     return o;
 }
 
-// diagnostic knobs, read from the environment once: BRIEF_WG_PER_CU (resident k_fused<TRAIN> workgroups per CU),
-// BRIEF_STAGGER (start delay per residency slot, units of s_sleep(127))
+// Diagnostic knobs (BRIEF_WG_PER_CU, BRIEF_STAGGER, BRIEF_DIAG, BRIEF_TAIL_ROUNDS, ...): read from the environment once, and ONLY in a
+// -DBRIEF_DIAGNOSTICS build (tools/ build their own library and point BRIEF_LIB at it).  The product library never calls getenv: no
+// environment variable can change what a fit computes or how it is launched (tests/test_host_logic.py checks the symbol table).
+#ifdef BRIEF_DIAGNOSTICS
+static const char *env_str(const char *name) { return getenv(name); }
+#else
+static const char *env_str(const char *) { return nullptr; }
+#endif
 static int env_int(const char *name, int dflt, int lo, int hi)
 {
-    const char *e = getenv(name);
+    const char *e = env_str(name);
     if (!e) return dflt;
     const int v = atoi(e);
     return v >= lo && v <= hi ? v : dflt;
 }
 static const int kRecWgsPerCu = 8;      // per-workgroup record slots per CU in the workspace (k_fused: body + single-tile tail)
 static const int g_wg_per_cu = env_int("BRIEF_WG_PER_CU", BRIEF_TRAIN_WPE, 1, 4);
-static const bool g_wg_per_cu_set = getenv("BRIEF_WG_PER_CU") != nullptr;
+static const bool g_wg_per_cu_set = env_str("BRIEF_WG_PER_CU") != nullptr;
 static const int g_stagger = env_int("BRIEF_STAGGER", 0, 0, 64);      // start delay per residency slot: measured neutral with two and with three workgroups per CU (profiles/r03_wg_timeline.md), off
 static const int g_diag = env_int("BRIEF_DIAG", 0, 0, 255);
 static const int g_x3_decode = env_int("BRIEF_X3_DECODE", 1, 0, 1);      // 0 (diagnostics): BRIEF_PREC_BF16X3 nets are evaluated by the f32 forward kernel
@@ -2862,7 +2868,7 @@ static int wgrad_splits(const brief_siren_desc &d, int64_t n)
 static bool use_small(const brief_siren_desc &d)
 {
     static int enabled = -1;
-    if (enabled < 0) { const char *e = getenv("BRIEF_SMALL"); enabled = (e && atoi(e) == 0) ? 0 : 1; }
+    if (enabled < 0) { const char *e = env_str("BRIEF_SMALL"); enabled = (e && atoi(e) == 0) ? 0 : 1; }
     return enabled && d.precision == BRIEF_PREC_F32 && brief_nt(d) <= 2 && d.layers - 2 <= 7;
 }
 static int small_hb(const brief_siren_desc &d)

@@ -214,7 +214,12 @@ class NFGR:
             if all(cl[i] == dims[i] for i in range(len(dims))):
                 sampler = "full"            # one window == the whole volume every step
             else:
-                index_stream = _CubeIndexStream(dims, cl, C_.sampler.cube_count, self.device)
+                # the window draws continue the CPU generator's stream behind the net's init draws, as in the reference
+                # (main.py:112 after reproduc + init_phi) — through a PRIVATE generator forked from it, so that the draws of
+                # one block do not depend on which other blocks are trained beside it, nor on checkpoint spacing / chunking
+                gen = torch.Generator()
+                gen.set_state(torch.get_rng_state())
+                index_stream = _CubeIndexStream(dims, cl, C_.sampler.cube_count, self.device, generator=gen)
         elif C_.sampler.name != "randompoint":
             raise NotImplementedError(C_.sampler.name)
         n_step = C_.sampler.sample_size if index_stream is None else index_stream.n
@@ -392,8 +397,8 @@ class NFGR:
         return chunks, assign_blocks(costs, world), (data if identity else pre), orig_sideinfos
 
     def _fit_blocks(self, chunks, owner, src, ext, checkpoints, marks=(), on_mark=None):
-        """main.py:547-607 for the blocks this rank owns.  Every block is prepared first (nets are initialised in partition
-        order, as a serial run would), then all of them are trained TOGETHER: brief_multi_fit spreads them over HIP streams
+        """main.py:547-607 for the blocks this rank owns.  Every block is prepared first (each from the job's seed, as the
+        reference's per-block processes do), then all of them are trained TOGETHER: brief_multi_fit spreads them over HIP streams
         so the launches of narrow nets overlap; the results per block are those of a fit on its own.  Blocks with option
         overrides (Compress.divide.exception) keep their own schedule and sampler: they are fitted one by one afterwards."""
         dist, rank, world = _dist()
@@ -410,6 +415,12 @@ class NFGR:
             sub_dir = opj(logdir, "subexps", c["name"])
             os.makedirs(sub_dir, exist_ok=True)
             block = np.ascontiguousarray(_orig_block(src, c))
+            # the reference fits every block in a process of its own that starts with reproduc(seed) (main.py:573, 653-661, 670):
+            # reseeding per block gives each block that generator state for its init and sampler draws, whichever rank owns it
+            # and whatever is trained beside it
+            seed = getattr(self.opt, "_seed", None)
+            if seed is not None:
+                torch.manual_seed(int(seed))
             mine.append((c, sub, sub_dir, sub.prepare_fit(opj(sub_dir, c["name"] + ext), data=block, logdir=sub_dir)))
             del block
         special = [m for m in mine if m[0]["name"] in exceptions]
@@ -684,7 +695,7 @@ def _append_csv(path, row):
 class _CubeIndexStream:
     """RandomCubeSampler with windows smaller than the volume (main.py:38-125): `unfold` enumerates the
     prod(dims - cube_len + 1) window origins in row-major order (d slowest); every step draws cube_count of them with
-    torch.randint on the GLOBAL CPU generator (main.py:112, seeded by reproduc) and yields the flat voxel indices of
+    torch.randint on the CPU generator (main.py:112, seeded by reproduc; NFGR.prepare_fit hands over a private fork of it) and yields the flat voxel indices of
     those windows, window after window, (ds, hs, ws) row-major inside a window.  Pinned: tests/golden/cube.npz."""
 
     def __init__(self, dims, cube_len, cube_count, device, generator=None):

@@ -214,6 +214,60 @@ def test_dividetask_cotrained_blocks_equal_serial_blocks(tmp_path, monkeypatch):
     assert runs["1"][1] == runs["0"][1]
 
 
+def test_dividetask_windowed_cube_blocks_do_not_depend_on_their_neighbours(tmp_path, monkeypatch):
+    """Blocks with a WINDOWED cube sampler (host-drawn window numbers): every block draws from a private fork of the CPU
+    generator taken after a per-block reproduc(seed) (main.py:573, 653-661: one process per block in the reference), so its
+    weight files are the same whether it is co-trained, trained block after block, trained with other checkpoint spacing,
+    or fitted on its own as a SingleTask of the sub-volume with the block's budget."""
+    from brief_pytorch_amd.synthetic import make_volume
+    vol = make_volume((16, 48, 32), seed=6)
+    path = str(tmp_path / "blk.tif")
+    save_img(path, vol)
+
+    def files_of(logdir, k):
+        mdir = os.path.join(logdir, "steps%d" % k, "compressed", "module")
+        return {(blk, f): open(os.path.join(mdir, blk, "module", f), "rb").read() for blk in sorted(os.listdir(mdir))
+                for f in sorted(os.listdir(os.path.join(mdir, blk, "module")))}
+
+    runs = {}
+    for tag, mode, ckpt in (("co", "1", "none"), ("serial", "0", "none"), ("co_ckpt", "1", "30,70")):
+        monkeypatch.setenv("BRIEF_COTRAIN", mode)
+        opt = _opt(tmp_path / tag, 120, ckpt, 30000.0)
+        cf = opt.CompressFramework
+        cf["_seed"] = 42
+        cf.Compress.divide.divide_type = "total_1_3_2"
+        cf.Compress.divide.param_alloc = "by_size"
+        cf.Compress.sampler.cube_len = [8, 8, 8]
+        cf.Compress.sampler.cube_count = 6
+        Log = MyLogger(**opt.Log)
+        torch.manual_seed(7)                 # whatever the caller's generator holds: the blocks reseed from the job's seed
+        NFGR(cf, Log=Log).compress_divide(path, opt)
+        runs[tag] = files_of(Log.logdir, 120)
+        Log.close()
+    assert len(runs["co"]) == 6 * 10
+    assert runs["co"] == runs["serial"] == runs["co_ckpt"]
+    # one block on its own: SingleTask on the sub-volume with the block's budget, after reproduc(42)
+    chunks = misc.divide_data(vol, "total_1_3_2")[0]
+    blk = chunks[3]
+    sizes = misc.alloc_param(chunks, 30000.0, "by_size") if hasattr(misc, "alloc_param") else None
+    side = config.load(os.path.join(str(tmp_path / "co" / "outputs"), os.listdir(str(tmp_path / "co" / "outputs"))[0],
+                                    "steps120", "compressed", "sideinfos", blk["name"], "sideinfos.yaml"))
+    opt = _opt(tmp_path / "solo", 120, "none", 0.0)
+    cf = opt.CompressFramework
+    cf["_seed"] = 42
+    cf.Compress.sampler.cube_len = [8, 8, 8]
+    cf.Compress.sampler.cube_count = 6
+    cf.Compress.param.given_size = 4.0 * SIREN.calc_param_count(3, 1, side["phi_features"], cf.Module.phi.layers)
+    sub_path = str(tmp_path / (blk["name"] + ".tif"))
+    save_img(sub_path, np.ascontiguousarray(blk["data"]))
+    Log = MyLogger(**opt.Log)
+    torch.manual_seed(42)
+    NFGR(cf, Log=Log).compress(sub_path)
+    mdir = os.path.join(Log.logdir, "steps120", "compressed", "module")
+    solo = {f: open(os.path.join(mdir, f), "rb").read() for f in sorted(os.listdir(mdir))}
+    assert solo == {f: raw for (b, f), raw in runs["co"].items() if b == blk["name"]}
+
+
 def test_dividetask_exception_overrides_one_block(tmp_path):
     """Compress.divide.exception (main.py:535-537, 568-569): a partial option tree merged into ONE block's task options.
     The other blocks' weight files stay byte-identical to the run without it; the overridden block is fitted with its own

@@ -98,6 +98,22 @@ def test_every_function_the_header_declares_is_exported():
     assert sorted(_lib.EXPORTS) == names
 
 
+def test_product_library_reads_no_environment_variable():
+    """Result- or launch-changing diagnostics (BRIEF_DIAG, BRIEF_TAIL_ROUNDS, BRIEF_WGRAD_REPEAT, ...) exist only in a
+    -DBRIEF_DIAGNOSTICS build: the shipped library must not import getenv at all."""
+    import os
+    import subprocess
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libbrief_hip.so not built")
+    if os.path.basename(_lib.LIB_PATH) != "libbrief_hip.so":
+        pytest.skip("BRIEF_LIB points at a diagnostic build")
+    syms = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "hipLaunchKernel" in syms or "hipModuleLaunchKernel" in syms      # the listing is what we think it is
+    assert "getenv" not in syms, "the product libbrief_hip.so imports getenv"
+    src = open(_lib.SRC).read() + open(os.path.join(os.path.dirname(_lib.SRC), "brief_bf16.inc")).read()
+    assert src.count("getenv(") == 1 and "#ifdef BRIEF_DIAGNOSTICS\nstatic const char *env_str(const char *name) { return getenv(name); }" in src
+
+
 def test_bf16_packed_layout_counts():
     """BRIEF_PREC_BF16: widths pad to 256 / 512 and the packed buffer grows by the bf16 W / W^T fragment copies
     (host-side layout arithmetic only: no GPU needed)"""
