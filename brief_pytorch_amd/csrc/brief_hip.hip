@@ -437,6 +437,9 @@ struct FusedLds {
     static constexpr int TOTAL = HW_OFF + 4 * K::FP + 4;
 };
 
+#ifndef BRIEF_FUSED64
+#define BRIEF_FUSED64 0      // 1: the 8-tile TRAIN step walks 64-sample tiles (k_lean<2, 2, 8>) instead of k_fused<8>'s 32-sample tiles
+#endif
 #ifndef BRIEF_KERNARG_RELOAD
 #define BRIEF_KERNARG_RELOAD 1
 #endif
@@ -1439,6 +1442,8 @@ __global__ __launch_bounds__(256, 2) void k_fused_x3(const FusedArgs a)
     }
 }
 
+#include "brief_lean.inc"
+
 // ---------------------------------------------------------------------------------------------
 // k_small<NT, HB>: the whole train step of a NARROW net (F <= 64: NT = 1, 2; at most HB hidden F x F layers)
 // without any HBM stash.  For these widths (every net the reference's own YAMLs produce: F = 22 ... 56) the
@@ -1456,18 +1461,18 @@ __global__ __launch_bounds__(256, 2) void k_fused_x3(const FusedArgs a)
 // (The scalars it needs are re-read from the kernarg segment through an opaque pointer at every call: kept live across a
 //  tile loop they get spilled to VGPR lanes and come back one v_readlane — a VALU instruction — at a time.)
 typedef const __attribute__((address_space(4))) FusedArgs *kargs_t;
-__device__ __forceinline__ void small_inputs(const FusedArgs &a_unused, int cin, int cout, int64_t n, float4 &xo, float4 &yo, float4 &wo)
+// AP: where the job's FusedArgs live — the kernarg segment (k_small: the kernel's only argument) or a table entry in global memory
+// (k_small_group: one entry per co-trained job); k_idx / rng_step: this step's index set and Philox step (per-step values)
+template <typename AP>
+__device__ __forceinline__ void small_inputs(AP ap, const int64_t *k_idx, uint64_t rng_step, int cin, int cout, int64_t n, float4 &xo, float4 &yo, float4 &wo)
 {
-    (void)a_unused;
-    kargs_t ap = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();      // FusedArgs is the kernels' only argument
     asm volatile("" : "+s"(ap));
     float x0 = 0.f, x1 = 0.f, x2 = 0.f;
     float yv[4] = {0.f, 0.f, 0.f, 0.f}, wv4[4] = {1.f, 1.f, 1.f, 1.f};
     if (n < ap->n) {
-        const int64_t *k_idx = ap->idx;
         const float *k_tg = ap->targets, *k_wt = ap->weights, *k_co = ap->coords;
         const uint64_t k_pop = ap->rng_pop;
-        const int64_t j = k_idx ? k_idx[n] : (k_pop ? philox_index(n, k_pop, ap->rng_seed, ap->rng_step) : n + ap->offset);
+        const int64_t j = k_idx ? k_idx[n] : (k_pop ? philox_index(n, k_pop, ap->rng_seed, rng_step) : n + ap->offset);
         if (!k_tg) {
             // forward-only launch: no targets
         } else if (cout == 1) {
@@ -1511,8 +1516,10 @@ struct SmallLds {
 };
 constexpr int small_wpe(int HB) { return HB <= 3 ? 2 : 1; }     // resident workgroups per CU (register budget)
 
-template <int NT, int HB>
-__global__ __launch_bounds__(256, small_wpe(HB)) void k_small(const FusedArgs a)
+// bid / gdim: this workgroup's number among, and the count of, the workgroups that serve THIS job (the whole grid for k_small; a
+// contiguous range of it for k_small_group)
+template <int NT, int HB, typename AP>
+__device__ __forceinline__ void small_body(const FusedArgs &a, AP ap_in, const int64_t *step_idx, uint64_t step_rng, int bid, int gdim)
 {
     static_assert(NT == 1 || NT == 2, "narrow nets only");
 #ifdef BRIEF_STAMPS
@@ -1568,12 +1575,12 @@ __global__ __launch_bounds__(256, small_wpe(HB)) void k_small(const FusedArgs a)
     const int64_t ntiles = (a.n + wg_samples - 1) / wg_samples;
     // (measured and not kept: fetching the next tile's inputs, or the next chain's first A fragments, one
     //  phase ahead costs more in registers -> scratch than the latency it hides)
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int64_t tile = bid; tile < ntiles; tile += gdim) {
         const int64_t n0 = (tile * K::WS + ws) * 32;
         const int64_t n = n0 + ln;
         const bool valid = n < a.n;
         float4 in_x, in_y, in_w;     // coords (x0,x1,x2,-) | targets | loss weights
-        small_inputs(a, cin, cout, n, in_x, in_y, in_w);
+        small_inputs(ap_in, step_idx, step_rng, cin, cout, n, in_x, in_y, in_w);
         const float x0 = in_x.x, x1 = in_x.y, x2 = in_x.z;
         const float yv[4] = {in_y.x, in_y.y, in_y.z, in_y.w}, wv4[4] = {in_w.x, in_w.y, in_w.z, in_w.w};
         f32x16 acc[1], hreg[1];
@@ -1802,7 +1809,7 @@ __global__ __launch_bounds__(256, small_wpe(HB)) void k_small(const FusedArgs a)
 #undef TILE_BARRIER
     // ---- per-wave record of the skinny gradients (format of k_fused: k_reduce reads both)
     {
-        float *rec = a.rec + ((int64_t)blockIdx.x * 4 + wave) * BRIEF_REC_FLOATS;
+        float *rec = a.rec + ((int64_t)bid * 4 + wave) * BRIEF_REC_FLOATS;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const float v0 = acc0[c] + __shfl_xor(acc0[c], 32);
@@ -1826,7 +1833,7 @@ __global__ __launch_bounds__(256, small_wpe(HB)) void k_small(const FusedArgs a)
 #pragma unroll
         for (int i = 0; i < HB; ++i) {
             if (i < L - 2) {
-                float *slab = a.slabs + ((int64_t)i * gridDim.x + blockIdx.x) * slab_sz;
+                float *slab = a.slabs + ((int64_t)i * gdim + bid) * slab_sz;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) slab[(32 * wm + ROWMAP(r, hi)) * K::FP + 32 * ws + ln] = dW[i][r];
                 const float tot = dbv[i] + __shfl_xor(dbv[i], 32);
@@ -1854,7 +1861,7 @@ __global__ __launch_bounds__(256, small_wpe(HB)) void k_small(const FusedArgs a)
                         for (int r = 0; r < 16; ++r) tsum[r] += red[(w - 1) * 1024 + r * 64 + lane];
                         bsum += redb[(w - 1) * 64 + lane];
                     }
-                    float *slab = a.slabs + ((int64_t)i * gridDim.x + blockIdx.x) * slab_sz;
+                    float *slab = a.slabs + ((int64_t)i * gdim + bid) * slab_sz;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) slab[ROWMAP(r, hi) * K::FP + ln] = tsum[r];
                     const float tot = bsum + __shfl_xor(bsum, 32);
@@ -1864,6 +1871,40 @@ __global__ __launch_bounds__(256, small_wpe(HB)) void k_small(const FusedArgs a)
             }
         }
     }
+}
+
+template <int NT, int HB>
+__global__ __launch_bounds__(256, small_wpe(HB)) void k_small(const FusedArgs a)
+{
+    kargs_t ap = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();      // FusedArgs is the kernel's only argument
+    small_body<NT, HB>(a, ap, a.idx, a.rng_step, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Co-trained narrow nets in ONE launch (brief_multi_fit; the per-block loop of main.py:547-575 for the blocks one GPU owns): job j is
+// served by workgroups [wg_begin[j], wg_begin[j + 1]) — exactly the grid, tile walk, records and slabs its own k_small launch would have,
+// so every job's results are bit-identical to a fit on its own.  The static part of a job (pointers, net, grid, loss) sits in a device
+// table uploaded once per brief_multi_fit call; what changes from step to step travels in the kernel arguments.
+#define BRIEF_GROUP_MAX 64
+struct SmallGroupArgs {
+    const FusedArgs *table;
+    int njobs;
+    int wg_begin[BRIEF_GROUP_MAX + 1];
+    uint64_t rng_step[BRIEF_GROUP_MAX];
+    const int64_t *idx[BRIEF_GROUP_MAX];
+};
+__device__ __forceinline__ int group_job(const int *begin, int njobs, int b)
+{
+    int j = 0;
+    for (int k = 1; k < njobs; ++k) j += (b >= begin[k]);      // begin[] is ascending
+    return j;
+}
+template <int NT, int HB>
+__global__ __launch_bounds__(256, small_wpe(HB)) void k_small_group(const SmallGroupArgs g)
+{
+    const int b = (int)blockIdx.x;
+    const int j = group_job(g.wg_begin, g.njobs, b);
+    const FusedArgs *tp = g.table + j;
+    small_body<NT, HB>(*tp, tp, g.idx[j], g.rng_step[j], b - g.wg_begin[j], g.wg_begin[j + 1] - g.wg_begin[j]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1881,8 +1922,9 @@ struct WgradArgs {
 
 // k_wgrad<NT> geometry.  Widths above 8 tiles are cut into NQ x NQ output quadrants of QT x QT tiles, one
 // workgroup each (a 512x512 fp32 dW does not fit eight waves' registers); QT plays NT's role inside.
-constexpr int wgrad_nq(int NT) { return NT > 8 ? 2 : 1; }
-constexpr int wgrad_qt(int NT) { return NT / wgrad_nq(NT); }
+constexpr int wgrad_nq(int NT) { return (NT + 7) / 8; }
+constexpr int wgrad_qt(int NT) { return (NT + wgrad_nq(NT) - 1) / wgrad_nq(NT); }      // exact for every compiled width (1 .. 8, 12, 16); above 16 tiles
+                                                                                        // (run-time width) the last quadrant row / column may be short
 // dynamic LDS in floats: two double-buffered panel pairs, or the k-slice fold area if larger
 constexpr int wgrad_lds_floats(int NT)
 {
@@ -1893,11 +1935,16 @@ constexpr int wgrad_lds_floats(int NT)
     return fold > panels ? fold : panels;
 }
 
-template <int NT>
+// NT > 0: compile-time width.  NT == 0: run-time width above 16 tiles (k_lean's nets), QTR tiles per quadrant side, ceil(nt / 8)
+// quadrants per side; the last quadrant row / column may hold fewer than QTR tiles (its missing rows are staged as zeros).
+template <int NT, int QTR = 0>
 __global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
 {
-    constexpr int FP = 32 * NT;
-    constexpr int NQ = wgrad_nq(NT), QT = wgrad_qt(NT), QP = 32 * QT;   // quadrants per side, tiles / rows per quadrant side
+    constexpr bool RTW = NT == 0;
+    const int nt_w = RTW ? brief_nt(a.d) : NT;
+    const int FP = 32 * nt_w;
+    const int NQ = RTW ? (nt_w + 7) / 8 : wgrad_nq(NT);
+    constexpr int QT = RTW ? QTR : wgrad_qt(NT), QP = 32 * QT;   // quadrants per side, tiles / rows per quadrant side
     // 8 waves = WMk x WNk output-tile grid x WK-way split of each chunk's four k-groups.  Wide nets spend
     // all 8 waves on output tiles; narrow ones (QT <= 4) would leave most waves without a tile, so they
     // split K instead and fold the partial accumulators through LDS at the end (fixed order).
@@ -1944,7 +1991,8 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
     // clamped to the last chunk instead of being skipped (the redundant copies are never read).
     // thread e fetches 16 bytes at e * 16 of the quadrant's rows; the chunk offset is a scalar (no per-load 64-bit address
     // arithmetic on the VALU, which the f32 MFMA shares)
-    const int panel_bytes = (int)((int64_t)FP * a.npad * 4) - (NQ - 1) * QP * 128;      // to the end of the last chunk's rows of the last quadrant
+    const int panel_bytes = (int)((int64_t)FP * a.npad * 4) - (RTW ? 0 : (NQ - 1) * QP * 128);      // to the end of the last chunk's rows of the last quadrant
+    const int rows_m = RTW ? FP - qm * QP : QP, rows_n = RTW ? FP - qn * QP : QP;      // rows this quadrant really has (run-time width: the last one may be short)
     const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void *)Dl, 0, panel_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc((void *)Zl, 0, panel_bytes, 0x00020000);
     int voffs[NLD];
@@ -1959,8 +2007,8 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
         ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);                                                  \
         rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);                                                  \
         if (FULL || e < QP * 8) {                                                                 \
-            ra[i] = bload4w(rsD, voffs[i], (int)((cc) * (FP * 128)));                                    \
-            rb[i] = bload4w(rsZ, voffs[i], (int)((cc) * (FP * 128)));                                    \
+            if (!RTW || (e >> 3) < rows_m) ra[i] = bload4w(rsD, voffs[i], (int)((cc) * (FP * 128)));     \
+            if (!RTW || (e >> 3) < rows_n) rb[i] = bload4w(rsZ, voffs[i], (int)((cc) * (FP * 128)));     \
         }                                                                                         \
     }
 #define WG_STAGE_A(buf, i)                                                                        \
@@ -2084,11 +2132,11 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int mt = wmk * TM + i;
-        if (mt < QT) {
+        if (mt < QT && (!RTW || qm * QT + mt < nt_w)) {
 #pragma unroll
             for (int jn = 0; jn < TN; ++jn) {
                 const int nt = wnk * TN + jn;
-                if (nt < QT) {
+                if (nt < QT && (!RTW || qn * QT + nt < nt_w)) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
                         slab[(int64_t)(qm * QP + 32 * mt + ROWMAP(r, hi)) * FP + qn * QP + 32 * nt + ln] = acc[i][jn][r];
@@ -2370,21 +2418,23 @@ __device__ __forceinline__ int64_t frag_index(int NT, int row, int col)
 // blocks [0, nb_hidden): one thread per hidden-layer parameter, nsplit slab terms each.
 // blocks [nb_hidden, ...): one WAVE per first-layer / head parameter (and one for the loss): these sum
 // over up to 2048 per-wave records, which a single thread would walk at one L2 latency per term.
-__global__ __launch_bounds__(1024) void k_reduce(const ReduceArgs a, int nb_hidden)
+// bid: this block's number among the blocks that serve THIS job (the whole grid for k_reduce); opt / loss_out: the step's optimizer
+// scalars and loss destination (per-step values: kernel arguments also in the grouped form)
+__device__ __forceinline__ void reduce_body(const ReduceArgs &a, const OptimScalars &opt, float *loss_out, int nb_hidden, int bid)
 {
     const brief_siren_desc &d = a.d;
     const int F = d.features, cin = d.cin, cout = d.cout;
     const int NT = brief_nt(d), FP = 32 * NT, WM = brief_wm(NT), WS = brief_ws(NT);
     const int64_t off_head = brief_canon_head_off(d);
     const int64_t l0_count = (int64_t)F * cin + F;
-    if ((int)blockIdx.x < nb_hidden) {
+    if (bid < nb_hidden) {
         // sgroups threads per parameter: thread (pl, sg) adds slabs sg, sg + sgroups, ...; group 0 then adds the
         // group sums in group order (fixed order: bit-reproducible)
         __shared__ float fold[1024];
         const int64_t hcount = off_head - l0_count;
         const int SG = a.sgroups, ppb = (int)blockDim.x / SG;      // ppb consecutive parameters per block: a group's loads stay coalesced
         const int pl = threadIdx.x % ppb, sg = threadIdx.x / ppb;
-        const int64_t hidx = (int64_t)blockIdx.x * ppb + pl;
+        const int64_t hidx = (int64_t)bid * ppb + pl;
         const bool live = hidx < hcount;
         const int64_t per = (int64_t)F * F + F;
         const int l = live ? 1 + (int)(hidx / per) : 1;
@@ -2414,7 +2464,7 @@ __global__ __launch_bounds__(1024) void k_reduce(const ReduceArgs a, int nb_hidd
         if (!live || sg != 0) return;
         a.grads[l0_count + hidx] = s;
         if (a.update) {
-            const float pv = optim_apply(a.opt, s, a.params, a.s1, a.s2, l0_count + hidx);
+            const float pv = optim_apply(opt, s, a.params, a.s1, a.s2, l0_count + hidx);
             float *blk = a.pk + brief_pk_hidden(d, l);
             if (r < (int64_t)F * F) {
                 const int o = (int)(r / F), i = (int)(r % F);
@@ -2451,13 +2501,14 @@ __global__ __launch_bounds__(1024) void k_reduce(const ReduceArgs a, int nb_hidd
     }
     // ---- skinny parameters: wave w of this block handles item (blockIdx - nb_hidden)*4 + w
     const int lane = threadIdx.x & 63;
-    const int64_t item = (int64_t)(blockIdx.x - nb_hidden) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t item = (int64_t)(bid - nb_hidden) * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t head_count = (int64_t)cout * F + cout;
     const int nrec = a.nrec_wg * WS;                 // records that carry a given feature tile / the loss
+    const int TR = brief_rec_tr(NT), rec_floats = brief_rec_floats(NT);      // record sections: dW0[TR][4] | dWh[4][TR] | dbh[4] | loss
     if (item > l0_count + head_count) return;
     int slot, wmo = 0;
     if (item == l0_count + head_count) {
-        slot = BRIEF_REC_LOSS;                        // loss (waves with wm == 0)
+        slot = 8 * TR + 4;                            // loss (waves with wm == 0)
     } else if (item < l0_count) {
         int o, c;
         if (item < (int64_t)F * cin) { o = (int)(item / cin); c = (int)(item % cin); }
@@ -2468,10 +2519,10 @@ __global__ __launch_bounds__(1024) void k_reduce(const ReduceArgs a, int nb_hidd
         const int64_t r = item - l0_count;
         if (r < (int64_t)cout * F) {
             const int c = (int)(r / F), o = (int)(r % F);
-            slot = BRIEF_REC_DWH + c * 128 + ((o >> 5) / WM) * 32 + (o & 31);
+            slot = 4 * TR + c * TR + ((o >> 5) / WM) * 32 + (o & 31);
             wmo = (o >> 5) % WM;
         } else {
-            slot = BRIEF_REC_DBH + (int)(r - (int64_t)cout * F);
+            slot = 8 * TR + (int)(r - (int64_t)cout * F);
         }
     }
     // record index of (wg, ws) for this wm: (wg*4 + ws*WM + wmo); enumerate q = wg*WS + ws
@@ -2479,15 +2530,15 @@ __global__ __launch_bounds__(1024) void k_reduce(const ReduceArgs a, int nb_hidd
 #pragma unroll 4
     for (int q = lane; q < nrec; q += 64) {      // (unrolled: the loads of a lane are independent, only the adds are ordered)
         const int wg = q / WS, w = q % WS;
-        s += a.rec[((int64_t)wg * 4 + w * WM + wmo) * BRIEF_REC_FLOATS + slot];
+        s += a.rec[((int64_t)wg * 4 + w * WM + wmo) * rec_floats + slot];
     }
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
     if (lane == 0) {
-        if (item == l0_count + head_count) { *a.loss_out = s * a.inv_count; return; }
+        if (item == l0_count + head_count) { *loss_out = s * a.inv_count; return; }
         const int64_t e = item < l0_count ? item : off_head + (item - l0_count);
         a.grads[e] = s;
         if (a.update) {
-            const float pv = optim_apply(a.opt, s, a.params, a.s1, a.s2, e);
+            const float pv = optim_apply(opt, s, a.params, a.s1, a.s2, e);
             if (item < l0_count) {
                 if (item < (int64_t)F * cin) a.pk[(item / cin) * 4 + (item % cin)] = brief_phase_scale(d, 0) * pv;     // W0p[o][c]
                 else a.pk[(item - (int64_t)F * cin) * 4 + 3] = brief_phase_scale(d, 0) * pv;                           // W0p[o][3] = bias
@@ -2499,6 +2550,27 @@ __global__ __launch_bounds__(1024) void k_reduce(const ReduceArgs a, int nb_hidd
             }
         }
     }
+}
+
+__global__ __launch_bounds__(1024) void k_reduce(const ReduceArgs a, int nb_hidden)
+{
+    reduce_body(a, a.opt, a.loss_out, nb_hidden, (int)blockIdx.x);
+}
+
+// the reductions of co-trained jobs in one launch (see k_small_group): job j owns blocks [blk_begin[j], blk_begin[j + 1])
+struct ReduceGroupArgs {
+    const ReduceArgs *table;
+    int njobs;
+    int blk_begin[BRIEF_GROUP_MAX + 1];
+    int nb_hidden[BRIEF_GROUP_MAX];
+    OptimScalars opt[BRIEF_GROUP_MAX];
+    float *loss_out[BRIEF_GROUP_MAX];
+};
+__global__ __launch_bounds__(1024) void k_reduce_group(const ReduceGroupArgs g)
+{
+    const int b = (int)blockIdx.x;
+    const int j = group_job(g.blk_begin, g.njobs, b);
+    reduce_body(g.table[j], g.opt[j], g.loss_out[j], g.nb_hidden[j], b - g.blk_begin[j]);
 }
 
 #include "brief_bf16.inc"
@@ -2744,7 +2816,9 @@ static int check_desc(const brief_siren_desc *d)
     if (d->cout < 1 || d->cout > 4) return fail(BRIEF_ERR_INVALID, "data_channel must be 1..4");
     if (d->layers < 2) return fail(BRIEF_ERR_INVALID, "layers must be >= 2");
     if (d->features < 1 || d->features > 32 * BRIEF_MAX_NT)
-        return fail(BRIEF_ERR_INVALID, "features must be 1..512 on the fused fp32 path");
+        return fail(BRIEF_ERR_INVALID, "features must be 1..1024 on the fused path");
+    if (d->precision == BRIEF_PREC_BF16 && d->features > 512)
+        return fail(BRIEF_ERR_INVALID, "BRIEF_PREC_BF16 supports features <= 512 (wider nets run in BRIEF_PREC_F32)");
     if (d->precision != BRIEF_PREC_F32 && d->precision != BRIEF_PREC_BF16 && d->precision != BRIEF_PREC_BF16X3)
         return fail(BRIEF_ERR_INVALID, "precision must be BRIEF_PREC_F32, BRIEF_PREC_BF16 or BRIEF_PREC_BF16X3");
     if (d->precision == BRIEF_PREC_BF16X3 && d->features > 256) return fail(BRIEF_ERR_INVALID, "BRIEF_PREC_BF16X3 supports features <= 256");
@@ -2815,6 +2889,7 @@ static const int g_reduce_sg_small = env_int("BRIEF_REDUCE_SG", 0, 0, 64);      
 // samples one workgroup tile covers: 32 per sample sub-tile; the split-precision TRAIN kernel walks 64-sample tiles
 static int64_t fused_wg_samples(const brief_siren_desc &d, bool train)
 {
+    if (brief_nt(d) > 16) return 32;                                                                  // k_lean<1, ...>: one 32-sample tile
     if (!train && d.precision == BRIEF_PREC_F32) return 32 * (4 / brief_wm_infer(brief_nt(d)));      // KCfg<NT, true>
     return brief_wg_samples(brief_nt(d));      // (the split-precision TRAIN kernel deals 32-sample half-tiles too, and walks them in pairs)
 }
@@ -2824,8 +2899,9 @@ static int fused_grid(const brief_siren_desc &d, int64_t n, bool train)
     const int64_t wgs_ = fused_wg_samples(d, train);
     const int64_t tiles = (n + wgs_ - 1) / wgs_;
     // resident workgroups per CU = what the kernel's launch bounds were compiled for (BRIEF_WG_PER_CU: diagnostics)
-    const int wpe = g_wg_per_cu_set ? g_wg_per_cu : (d.precision == BRIEF_PREC_BF16X3 && (train || g_x3_decode) ? 2 /* k_fused_x3 */ : (train ? fused_train_wpe(nt) : (nt > 8 ? 2 : 3)));
-    const int64_t cap = (int64_t)kCUs * (train && nt > 8 ? 1 : wpe);      // TRAIN > 8 tiles: 512-register kernel, one workgroup per CU
+    const int wpe = g_wg_per_cu_set ? g_wg_per_cu : (d.precision == BRIEF_PREC_BF16X3 && (train || g_x3_decode) ? 2 /* k_fused_x3 */ :
+                    (BRIEF_FUSED64 && train && nt == 8 ? 2 /* k_lean<2, 2, 8> */ : (train ? fused_train_wpe(nt) : (nt > 8 ? 2 : 3))));
+    const int64_t cap = (int64_t)kCUs * ((train && nt > 8) || nt > 16 ? 1 : wpe);      // TRAIN > 8 tiles: 512-register kernel, one workgroup per CU; > 16 tiles: the image fills the CU's LDS
     return (int)(tiles < cap ? (tiles > 0 ? tiles : 1) : cap);
 }
 // k_fused<TRAIN> launch plan: a persistent body of `cap` workgroups over whole rounds of tiles, the rest of the batch
@@ -2876,13 +2952,23 @@ static int small_hb(const brief_siren_desc &d)
     const int h = d.layers - 2;
     return h <= 1 ? 1 : (h <= 3 ? 3 : (h <= 5 ? 5 : 7));
 }
+// Workgroups (= gradient slabs) of a narrow-net step: a function of the job alone (never of what is trained beside it: a co-trained
+// job uses the grid, tile walk and slab order of a fit on its own, bit for bit).  The tiles are spread evenly over the fewest rounds
+// the resident capacity allows, but at least two per workgroup: a batch of up to 2 x capacity tiles takes the time of two tile
+// passes with either count, and the many tiny blocks of a DivideTask — which share one k_small_group launch — then carry half
+// the workgroup prologues, slab writes and k_reduce terms (round 4; it was min(tiles, capacity): one tile per workgroup for small jobs).
 static int small_grid(const brief_siren_desc &d, int64_t n)
 {
     const int nt = brief_nt(d);
-    const int64_t tiles = (n + brief_wg_samples(nt) - 1) / brief_wg_samples(nt);
+    int64_t tiles = (n + brief_wg_samples(nt) - 1) / brief_wg_samples(nt);
+    if (tiles < 1) tiles = 1;
     const int64_t cap = (int64_t)kCUs * small_wpe(small_hb(d));
-    return (int)(tiles < cap ? (tiles > 0 ? tiles : 1) : cap);
+    int64_t rounds = (tiles + cap - 1) / cap;
+    if (rounds < 2) rounds = 2;
+    return (int)((tiles + rounds - 1) / rounds);
 }
+// device table of a co-trained group (k_small_group / k_reduce_group): lives at the end of the FIRST job's workspace
+static const int64_t kGroupTableFloats = (int64_t)BRIEF_GROUP_MAX * ((sizeof(FusedArgs) + sizeof(ReduceArgs) + 15) / 16 * 4 + 8);
 
 // ---- bf16 path geometry: 128-sample workgroup tiles, one workgroup per CU; stashes in bf16 (2 per float slot)
 static int64_t npad16(int64_t n) { return (n + 127) / 128 * 128; }
@@ -2934,11 +3020,11 @@ static Ws16 ws16_layout(const brief_siren_desc &d, int64_t n)
     return w;
 }
 
-struct WsLayout { int64_t z, dd, rec, slabs, total; };
+struct WsLayout { int64_t z, dd, rec, slabs, table, total; };
 static WsLayout ws_layout(const brief_siren_desc &d, int64_t n)
 {
     if (d.precision == BRIEF_PREC_BF16) {
-        WsLayout w; w.z = w.dd = w.rec = w.slabs = 0; w.total = ws16_layout(d, n).total;
+        WsLayout w; w.z = w.dd = w.rec = w.slabs = w.table = 0; w.total = ws16_layout(d, n).total;
         return w;
     }
     const int nt = brief_nt(d);
@@ -2948,8 +3034,10 @@ static WsLayout ws_layout(const brief_siren_desc &d, int64_t n)
     w.z = 0;
     w.dd = w.z + (small ? 0 : hidden * FP * npad);
     w.rec = w.dd + (small ? 0 : hidden * FP * npad);
-    w.slabs = w.rec + (int64_t)kCUs * kRecWgsPerCu * 4 * BRIEF_REC_FLOATS;
-    w.total = w.slabs + hidden * (int64_t)(small ? small_grid(d, n) : wgrad_splits(d, n)) * (FP * FP + FP);
+    w.slabs = w.rec + (int64_t)kCUs * kRecWgsPerCu * 4 * brief_rec_floats(nt);
+    w.table = w.slabs + hidden * (int64_t)(small ? small_grid(d, n) : wgrad_splits(d, n)) * (FP * FP + FP);
+    w.table = (w.table + 3) / 4 * 4;
+    w.total = w.table + (small ? kGroupTableFloats : 0);
     return w;
 }
 
@@ -3015,6 +3103,43 @@ static int launch_fused(const FusedArgs &fa, int grid, hipStream_t st)
         const size_t lds = sizeof(float) * FusedLds<NTV, !TRAIN>::TOTAL;                                 \
         hipLaunchKernelGGL((k_fused<NTV, TRAIN>), dim3(grid), dim3(256), lds, st, fa);                   \
         break;                                                                                           \
+    }
+#if BRIEF_FUSED64
+    if (nt == 8 && TRAIN) {
+        // 64-sample tiles for the 8-tile TRAIN kernel (k_lean<2, 2, 8>: every weight fragment against two sample halves)
+        const size_t lds = sizeof(float) * lean_lds(2, 2, 8).total;
+        static bool attr_64 = false;
+        if (!attr_64) {
+            HIP_TRY(hipFuncSetAttribute((const void *)k_lean<2, 2, 8, TRAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_64 = true;
+        }
+        hipLaunchKernelGGL((k_lean<2, 2, 8, TRAIN>), dim3(grid), dim3(256), lds, st, fa);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+#endif
+    if (nt > 16) {
+        // above 512 features: k_lean<1, MTW, 0>, a run-time number of feature tiles, MTW = ceil(nt / 4) of them per wave
+        const int mtw = (nt + 3) / 4;
+        const size_t lds = sizeof(float) * lean_lds(1, mtw, nt).total;
+        static bool attr_w[9] = {};
+#define BRIEF_WIDE(MTWV)                                                                                 \
+    case MTWV: {                                                                                         \
+        if (!attr_w[MTWV]) {                                                                             \
+            HIP_TRY(hipFuncSetAttribute((const void *)k_lean<1, MTWV, 0, TRAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                        (int)(sizeof(float) * lean_lds(1, MTWV, 4 * MTWV).total)));      \
+            attr_w[MTWV] = true;                                                                         \
+        }                                                                                                \
+        hipLaunchKernelGGL((k_lean<1, MTWV, 0, TRAIN>), dim3(grid), dim3(256), lds, st, fa);             \
+        break;                                                                                           \
+    }
+        switch (mtw) {
+            BRIEF_WIDE(5) BRIEF_WIDE(6) BRIEF_WIDE(7) BRIEF_WIDE(8)
+        default: return fail(BRIEF_ERR_INVALID, "unsupported width");
+        }
+#undef BRIEF_WIDE
+        HIP_TRY(hipGetLastError());
+        return 0;
     }
     switch (nt) {
         BRIEF_CASE(1) BRIEF_CASE(2) BRIEF_CASE(3) BRIEF_CASE(4)
@@ -3131,10 +3256,13 @@ struct UpdatePayload { OptimScalars opt; float *params, *s1, *s2, *pk; };
 
 }   // extern "C"
 
+// what one narrow-net step launches, as data: brief_multi_fit collects these for a group of jobs and launches them together
+struct SmallStepPlan { FusedArgs fa; ReduceArgs ra; int grid1, nb_hidden, nb_reduce, nt, hb; };
+
 static int train_step_impl(const brief_siren_desc *d, const float *packed, const brief_grid_desc *grid,
                            const brief_batch_desc *batch, int loss_kind, float thr, float beta,
                            float *grads, float *loss_out, float *yhat_out,
-                           void *workspace, int64_t workspace_bytes, void *stream, const UpdatePayload *upd)
+                           void *workspace, int64_t workspace_bytes, void *stream, const UpdatePayload *upd, SmallStepPlan *plan_only = nullptr)
 {
     if (int rc = check_desc(d)) return rc;
     if (int rc = check_batch(d, grid, batch, true)) return rc;
@@ -3232,41 +3360,6 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
     fa.rec = ws + wl.rec; fa.slabs = ws + wl.slabs; fa.yhat_out = yhat_out;
     fa.stagger_cus = kCUs; fa.stagger = g_stagger; fa.diag = g_diag;
     fa.pers_wgs = fp.pers_wgs; fa.pers_tiles = fp.pers_tiles;
-    const bool prof = g_prof_on && g_prof_n < kProfSlots;
-    if (prof) HIP_TRY(hipEventRecord(g_prof_ev[2 * g_prof_n], st));
-    if (small) {
-        const int hb = small_hb(*d);
-#define BRIEF_CASE(NTV, HBV)                                                                                        \
-    if (nt == NTV && hb == HBV)                                                                                     \
-        hipLaunchKernelGGL((k_small<NTV, HBV>), dim3(grid1), dim3(256), sizeof(float) * SmallLds<NTV>::TOTAL, st, fa);
-        BRIEF_CASE(1, 1) BRIEF_CASE(1, 3) BRIEF_CASE(1, 5) BRIEF_CASE(1, 7)
-        BRIEF_CASE(2, 1) BRIEF_CASE(2, 3) BRIEF_CASE(2, 5) BRIEF_CASE(2, 7)
-#undef BRIEF_CASE
-        HIP_TRY(hipGetLastError());
-    } else if (int rc = launch_fused<true>(fa, grid1, st)) return rc;
-    if (prof) { HIP_TRY(hipEventRecord(g_prof_ev[2 * g_prof_n + 1], st)); ++g_prof_n; }
-
-    if (!small && nsplit > 0) {
-        WgradArgs wa;
-        memset(&wa, 0, sizeof(wa));
-        wa.d = *d; wa.Z = fa.Z; wa.D = fa.D; wa.npad = fa.npad; wa.nsplit = nsplit; wa.slabs = ws + wl.slabs;
-        wa.stamps = ws + wl.rec + (int64_t)kCUs * kRecWgsPerCu * 4 * BRIEF_REC_FLOATS - 256 * 8 * 8;   // tail of the record region (diagnostics)
-        const int blocks = nsplit * (d->layers - 2) * wgrad_nq(nt) * wgrad_nq(nt);
-        if (d->precision == BRIEF_PREC_BF16X3) {
-            for (int rep = 0; rep < g_wgrad_repeat; ++rep)      // BRIEF_WGRAD_REPEAT (diagnostics): the launch is idempotent
-                hipLaunchKernelGGL(k_wgrad_x3, dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(8), st, wa);
-        } else
-#define BRIEF_CASE(NTV)                                                                                    \
-    case NTV:                                                                                              \
-        hipLaunchKernelGGL((k_wgrad<NTV>), dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(NTV), st, wa); \
-        break;
-        switch (nt) {
-            BRIEF_CASE(1) BRIEF_CASE(2) BRIEF_CASE(3) BRIEF_CASE(4)
-            BRIEF_CASE(5) BRIEF_CASE(6) BRIEF_CASE(7) BRIEF_CASE(8) BRIEF_CASE(12) BRIEF_CASE(16)
-        }
-#undef BRIEF_CASE
-        HIP_TRY(hipGetLastError());
-    }
     ReduceArgs ra;
     memset(&ra, 0, sizeof(ra));
     ra.d = *d; ra.rec = fa.rec; ra.nrec_wg = grid1; ra.slabs = ws + wl.slabs; ra.nsplit = nsplit;
@@ -3288,6 +3381,57 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
     const int nb_hidden = (int)((hcount + ppb - 1) / ppb);
     const int wpb = rthreads / 64;                     // skinny items (one wave each) per block
     const int nb_skinny = (int)((skinny + wpb - 1) / wpb);
+    if (plan_only) {
+        if (!small) return fail(BRIEF_ERR_INVALID, "internal: step plans exist for narrow nets only");
+        plan_only->fa = fa; plan_only->ra = ra; plan_only->grid1 = grid1; plan_only->nb_hidden = nb_hidden;
+        plan_only->nb_reduce = nb_hidden + nb_skinny; plan_only->nt = nt; plan_only->hb = small_hb(*d);
+        return 0;
+    }
+    const bool prof = g_prof_on && g_prof_n < kProfSlots;
+    if (prof) HIP_TRY(hipEventRecord(g_prof_ev[2 * g_prof_n], st));
+    if (small) {
+        const int hb = small_hb(*d);
+#define BRIEF_CASE(NTV, HBV)                                                                                        \
+    if (nt == NTV && hb == HBV)                                                                                     \
+        hipLaunchKernelGGL((k_small<NTV, HBV>), dim3(grid1), dim3(256), sizeof(float) * SmallLds<NTV>::TOTAL, st, fa);
+        BRIEF_CASE(1, 1) BRIEF_CASE(1, 3) BRIEF_CASE(1, 5) BRIEF_CASE(1, 7)
+        BRIEF_CASE(2, 1) BRIEF_CASE(2, 3) BRIEF_CASE(2, 5) BRIEF_CASE(2, 7)
+#undef BRIEF_CASE
+        HIP_TRY(hipGetLastError());
+    } else if (int rc = launch_fused<true>(fa, grid1, st)) return rc;
+    if (prof) { HIP_TRY(hipEventRecord(g_prof_ev[2 * g_prof_n + 1], st)); ++g_prof_n; }
+
+    if (!small && nsplit > 0) {
+        WgradArgs wa;
+        memset(&wa, 0, sizeof(wa));
+        wa.d = *d; wa.Z = fa.Z; wa.D = fa.D; wa.npad = fa.npad; wa.nsplit = nsplit; wa.slabs = ws + wl.slabs;
+        wa.stamps = ws + wl.rec + (int64_t)kCUs * kRecWgsPerCu * 4 * brief_rec_floats(nt) - 256 * 8 * 8;   // tail of the record region (diagnostics)
+        const int blocks = nsplit * (d->layers - 2) * wgrad_nq(nt) * wgrad_nq(nt);
+        if (d->precision == BRIEF_PREC_BF16X3) {
+            for (int rep = 0; rep < g_wgrad_repeat; ++rep)      // BRIEF_WGRAD_REPEAT (diagnostics): the launch is idempotent
+                hipLaunchKernelGGL(k_wgrad_x3, dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(8), st, wa);
+        } else
+#define BRIEF_CASE(NTV)                                                                                    \
+    case NTV:                                                                                              \
+        hipLaunchKernelGGL((k_wgrad<NTV>), dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(NTV), st, wa); \
+        break;
+        if (nt > 16) {
+            // run-time width: ceil(nt / 8) quadrants per side of QT = ceil(nt / quadrants) tiles (the last row / column may be short)
+            const int qt = (nt + wgrad_nq(nt) - 1) / wgrad_nq(nt);
+            switch (qt) {
+            case 6: hipLaunchKernelGGL((k_wgrad<0, 6>), dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(6), st, wa); break;
+            case 7: hipLaunchKernelGGL((k_wgrad<0, 7>), dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(7), st, wa); break;
+            case 8: hipLaunchKernelGGL((k_wgrad<0, 8>), dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(8), st, wa); break;
+            default: return fail(BRIEF_ERR_INVALID, "unsupported width");
+            }
+        } else
+        switch (nt) {
+            BRIEF_CASE(1) BRIEF_CASE(2) BRIEF_CASE(3) BRIEF_CASE(4)
+            BRIEF_CASE(5) BRIEF_CASE(6) BRIEF_CASE(7) BRIEF_CASE(8) BRIEF_CASE(12) BRIEF_CASE(16)
+        }
+#undef BRIEF_CASE
+        HIP_TRY(hipGetLastError());
+    }
     hipLaunchKernelGGL(k_reduce, dim3(nb_hidden + nb_skinny), dim3(rthreads), 0, st, ra, nb_hidden);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -3329,8 +3473,8 @@ static int fit_job_check(const brief_fit_job *j)
     return 0;
 }
 
-// one optimizer step (number t, 1-based) of a job on stream st; *lr is the running MultiStepLR value
-static int fit_job_step(const brief_fit_job *j, int64_t t, int64_t k, double *lr, hipStream_t st)
+// the learning rate in force for optimizer step t (1-based; entry k of this call): *lr is the running MultiStepLR value
+static void fit_job_lr(const brief_fit_job *j, int64_t t, int64_t k, double *lr)
 {
     // scheduler.step() calls made so far = t - 1: apply the milestones that were hit by the last one
     if (j->lr_table) *lr = j->lr_table[k];
@@ -3339,6 +3483,12 @@ static int fit_job_step(const brief_fit_job *j, int64_t t, int64_t k, double *lr
         for (int m = 0; m < j->n_milestones; ++m) hits += (j->milestones[m] == t - 1);
         if (hits) *lr = *lr * pow(j->gamma, (double)hits);
     }
+}
+
+// one optimizer step (number t, 1-based) of a job on stream st
+static int fit_job_step(const brief_fit_job *j, int64_t t, int64_t k, double *lr, hipStream_t st)
+{
+    fit_job_lr(j, t, k, lr);
     brief_batch_desc b = j->batch;
     if (b.idx) b.idx = b.idx + k * j->idx_stride;          // device-resident index stream: this step's set
     else if (b.rng_pop > 0) b.rng_step = (uint64_t)t;
@@ -3356,6 +3506,83 @@ int brief_siren_fit(const brief_fit_job *job, int64_t steps, void *stream)
         if (int rc = fit_job_step(job, job->t0 + 1 + k, k, &lr, (hipStream_t)stream)) return rc;
     if (job->loss_log && steps > 0)
         HIP_TRY(hipMemcpyAsync(job->loss_out, job->loss_log + steps - 1, sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
+// ---- co-trained narrow nets: one k_small_group + one k_reduce_group launch per step for a whole group of jobs -------------------
+}   // extern "C" (templates need C++ linkage)
+template <typename T>
+__global__ void k_put(T *dst, const T v)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) *dst = v;
+}
+extern "C" {
+
+struct FitGroup { int nt, hb, njobs, jobs[BRIEF_GROUP_MAX]; int small_grid_total, reduce_grid_total; FusedArgs *fa_table; ReduceArgs *ra_table;
+                  SmallGroupArgs sg; ReduceGroupArgs rg; };
+
+// the job's step as data (what brief_siren_fit_step would launch), validated the same way
+static int fit_job_plan(const brief_fit_job *j, SmallStepPlan *plan)
+{
+    if (j->optim_kind < BRIEF_OPT_ADAMAX || j->optim_kind > BRIEF_OPT_SGD) return fail(BRIEF_ERR_INVALID, "bad optimizer kind");
+    if (j->optim_kind != BRIEF_OPT_SGD && (!j->state1 || !j->state2)) return fail(BRIEF_ERR_INVALID, "optimizer state required");
+    UpdatePayload up;
+    up.opt = optim_scalars(j->optim_kind, j->lr, j->beta1, j->beta2, j->eps, j->t0 + 1);      // (replaced per step)
+    up.params = j->params; up.s1 = j->state1; up.s2 = j->state2; up.pk = j->packed;
+    return train_step_impl(&j->desc, j->packed, &j->grid, &j->batch, j->loss_kind, j->thr, j->beta, j->grads, j->loss_out, nullptr,
+                           j->workspace, j->workspace_bytes, nullptr, &up, plan);
+}
+
+// tables of a group -> the first job's workspace (one tiny launch per job: the values travel as kernel arguments, no host buffer has to
+// outlive the call), and the static halves of the two launches' arguments
+static int fit_group_init(FitGroup &g, const brief_fit_job *jobs, hipStream_t st)
+{
+    const brief_fit_job &j0 = jobs[g.jobs[0]];
+    const WsLayout wl0 = ws_layout(j0.desc, j0.batch.n);
+    char *base = (char *)((float *)j0.workspace + wl0.table);
+    g.fa_table = (FusedArgs *)base;
+    g.ra_table = (ReduceArgs *)(base + ((size_t)BRIEF_GROUP_MAX * sizeof(FusedArgs) + 15) / 16 * 16);
+    memset(&g.sg, 0, sizeof(g.sg));
+    memset(&g.rg, 0, sizeof(g.rg));
+    g.sg.table = g.fa_table; g.sg.njobs = g.njobs;
+    g.rg.table = g.ra_table; g.rg.njobs = g.njobs;
+    int wg = 0, rb = 0;
+    for (int i = 0; i < g.njobs; ++i) {
+        SmallStepPlan p;
+        if (int rc = fit_job_plan(&jobs[g.jobs[i]], &p)) return rc;
+        if (p.nt != g.nt || p.hb != g.hb) return fail(BRIEF_ERR_INVALID, "internal: mixed kernel variants in one group");
+        hipLaunchKernelGGL(k_put<FusedArgs>, dim3(1), dim3(64), 0, st, g.fa_table + i, p.fa);
+        hipLaunchKernelGGL(k_put<ReduceArgs>, dim3(1), dim3(64), 0, st, g.ra_table + i, p.ra);
+        g.sg.wg_begin[i] = wg; wg += p.grid1;
+        g.rg.blk_begin[i] = rb; rb += p.nb_reduce;
+        g.rg.nb_hidden[i] = p.nb_hidden;
+    }
+    g.sg.wg_begin[g.njobs] = wg; g.rg.blk_begin[g.njobs] = rb;
+    g.small_grid_total = wg; g.reduce_grid_total = rb;
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// step number k of this call for every job of the group: two launches
+static int fit_group_step(FitGroup &g, const brief_fit_job *jobs, int64_t k, double *lrs, hipStream_t st)
+{
+    for (int i = 0; i < g.njobs; ++i) {
+        const brief_fit_job *j = &jobs[g.jobs[i]];
+        const int64_t t = j->t0 + 1 + k;
+        fit_job_lr(j, t, k, &lrs[g.jobs[i]]);
+        g.sg.rng_step[i] = (uint64_t)t;
+        g.sg.idx[i] = j->batch.idx ? j->batch.idx + k * j->idx_stride : nullptr;
+        g.rg.opt[i] = optim_scalars(j->optim_kind, lrs[g.jobs[i]], j->beta1_table ? j->beta1_table[k] : j->beta1, j->beta2, j->eps, t);
+        g.rg.loss_out[i] = j->loss_log ? j->loss_log + k : j->loss_out;
+    }
+#define BRIEF_CASE(NTV, HBV)                                                                                        \
+    if (g.nt == NTV && g.hb == HBV)                                                                                 \
+        hipLaunchKernelGGL((k_small_group<NTV, HBV>), dim3(g.small_grid_total), dim3(256), sizeof(float) * SmallLds<NTV>::TOTAL, st, g.sg);
+    BRIEF_CASE(1, 1) BRIEF_CASE(1, 3) BRIEF_CASE(1, 5) BRIEF_CASE(1, 7)
+    BRIEF_CASE(2, 1) BRIEF_CASE(2, 3) BRIEF_CASE(2, 5) BRIEF_CASE(2, 7)
+#undef BRIEF_CASE
+    hipLaunchKernelGGL(k_reduce_group, dim3(g.reduce_grid_total), dim3(256), 0, st, g.rg);
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 
@@ -3377,24 +3604,58 @@ int brief_multi_fit(const brief_fit_job *jobs, int32_t njobs, int64_t steps, voi
         for (int s = 0; s <= kPoolStreams; ++s) HIP_TRY(hipEventCreateWithFlags(&g_pool_ev[s], hipEventDisableTiming));
         g_pool_init = true;
     }
+    // Units of work: GROUPS of narrow nets of one kernel variant (k_small_group: one launch per step for up to BRIEF_GROUP_MAX jobs —
+    // the many small blocks of a DivideTask, where a launch pair per block and step left the GPU waiting for the host) and single
+    // jobs (everything else: their own launches).  Unit u runs on internal stream u mod 8.
+    FitGroup *groups = (FitGroup *)malloc(sizeof(FitGroup) * (size_t)njobs);
+    int *unit_of = (int *)malloc(sizeof(int) * (size_t)njobs);          // job -> unit (group id, or -1 - single index)
+    double *lrs = (double *)malloc(sizeof(double) * (size_t)njobs);
+    if (!groups || !unit_of || !lrs) { free(groups); free(unit_of); free(lrs); return fail(BRIEF_ERR_INVALID, "out of host memory"); }
+    int ngroups = 0;
+    for (int j = 0; j < njobs; ++j) {
+        lrs[j] = jobs[j].lr;
+        unit_of[j] = -1;
+        if (!use_small(jobs[j].desc) || (g_prof_on && g_prof_n < kProfSlots)) continue;      // (timed runs keep their per-job launches)
+        const int nt = brief_nt(jobs[j].desc), hb = small_hb(jobs[j].desc);
+        int gi = -1;
+        for (int q = ngroups - 1; q >= 0; --q)
+            if (groups[q].nt == nt && groups[q].hb == hb) { if (groups[q].njobs < BRIEF_GROUP_MAX) gi = q; break; }
+        if (gi < 0) { gi = ngroups++; groups[gi].nt = nt; groups[gi].hb = hb; groups[gi].njobs = 0; }
+        groups[gi].jobs[groups[gi].njobs++] = j;
+        unit_of[j] = gi;
+    }
+    for (int q = 0; q < ngroups; ++q)
+        if (groups[q].njobs == 1) { unit_of[groups[q].jobs[0]] = -1; groups[q].njobs = 0; }      // a group of one: plain launches
+    // stream slots: groups first, then the single jobs
+    int nunits = 0;
+    int *gslot = (int *)malloc(sizeof(int) * (size_t)(ngroups + 1));
+    if (!gslot) { free(groups); free(unit_of); free(lrs); return fail(BRIEF_ERR_INVALID, "out of host memory"); }
+    for (int q = 0; q < ngroups; ++q) gslot[q] = groups[q].njobs ? nunits++ : -1;
+    for (int j = 0; j < njobs; ++j)
+        if (unit_of[j] < 0) unit_of[j] = -1 - (nunits++);
+    const int ns = nunits < kPoolStreams ? nunits : kPoolStreams;
     hipStream_t caller = (hipStream_t)stream;
-    const int ns = njobs < kPoolStreams ? njobs : kPoolStreams;
-    // fork: everything already queued on the caller's stream happens before the first step of every job
-    HIP_TRY(hipEventRecord(g_pool_ev[kPoolStreams], caller));
-    for (int s = 0; s < ns; ++s) HIP_TRY(hipStreamWaitEvent(g_pool[s], g_pool_ev[kPoolStreams], 0));
-    double *lrs = (double *)malloc(sizeof(double) * njobs);
-    if (!lrs) return fail(BRIEF_ERR_INVALID, "out of host memory");
-    for (int j = 0; j < njobs; ++j) lrs[j] = jobs[j].lr;
     int rc = 0;
+    // fork: everything already queued on the caller's stream happens before the first step of every job
+    if (hipEventRecord(g_pool_ev[kPoolStreams], caller) != hipSuccess) rc = fail(BRIEF_ERR_LAUNCH, "hipEventRecord");
+    for (int s = 0; s < ns && !rc; ++s)
+        if (hipStreamWaitEvent(g_pool[s], g_pool_ev[kPoolStreams], 0) != hipSuccess) rc = fail(BRIEF_ERR_LAUNCH, "hipStreamWaitEvent");
+    for (int q = 0; q < ngroups && !rc; ++q)
+        if (groups[q].njobs) rc = fit_group_init(groups[q], jobs, g_pool[gslot[q] % ns]);
     // step-major order: the host feeds all streams evenly instead of running ahead on one of them
-    for (int64_t k = 0; k < steps && !rc; ++k)
+    for (int64_t k = 0; k < steps && !rc; ++k) {
+        for (int q = 0; q < ngroups && !rc; ++q)
+            if (groups[q].njobs) rc = fit_group_step(groups[q], jobs, k, lrs, g_pool[gslot[q] % ns]);
         for (int j = 0; j < njobs && !rc; ++j)
-            rc = fit_job_step(&jobs[j], jobs[j].t0 + 1 + k, k, &lrs[j], g_pool[j % ns]);
-    free(lrs);
-    for (int j = 0; j < njobs && !rc && steps > 0; ++j)
+            if (unit_of[j] < 0) rc = fit_job_step(&jobs[j], jobs[j].t0 + 1 + k, k, &lrs[j], g_pool[(-1 - unit_of[j]) % ns]);
+    }
+    for (int j = 0; j < njobs && !rc && steps > 0; ++j) {
+        hipStream_t sj = g_pool[(unit_of[j] < 0 ? -1 - unit_of[j] : gslot[unit_of[j]]) % ns];
         if (jobs[j].loss_log &&
-            hipMemcpyAsync(jobs[j].loss_out, jobs[j].loss_log + steps - 1, sizeof(float), hipMemcpyDeviceToDevice, g_pool[j % ns]) != hipSuccess)
+            hipMemcpyAsync(jobs[j].loss_out, jobs[j].loss_log + steps - 1, sizeof(float), hipMemcpyDeviceToDevice, sj) != hipSuccess)
             rc = fail(BRIEF_ERR_LAUNCH, "hipMemcpyAsync");
+    }
+    free(groups); free(unit_of); free(lrs); free(gslot);
     // join (also on error: whatever was queued must be ordered before the caller's next work)
     for (int s = 0; s < ns; ++s) {
         HIP_TRY(hipEventRecord(g_pool_ev[s], g_pool[s]));

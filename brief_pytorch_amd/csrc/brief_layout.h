@@ -10,13 +10,16 @@
 #define BL_HD static inline
 #endif
 
-#define BRIEF_MAX_NT 16         // features <= 512 (widths above 256 are padded to 384 or 512)
-// per-wave partial record of the fused kernel: dW0[128 local features][4] | dWh[4][128] | dbh[4] | loss | stamps
+#define BRIEF_MAX_NT 32         // features <= 1024 (257 .. 512 are padded to 384 or 512 features; above 512 the tile count is exact)
+// per-wave partial record of the fused kernels: dW0[TR local features][4] | dWh[4][TR] | dbh[4] | loss | stamps, TR = 128 local
+// features per wave (4 feature tiles) up to 512 features, 256 (8 tiles) above: brief_rec_tr.  The constants are the TR = 128 case.
 #define BRIEF_REC_FLOATS 1056
 #define BRIEF_REC_DWH 512
 #define BRIEF_REC_DBH 1024
 #define BRIEF_REC_LOSS 1028
 #define BRIEF_REC_STAMPS 1030
+BL_HD int brief_rec_tr(int nt) { return nt > 16 ? 256 : 128; }
+BL_HD int brief_rec_floats(int nt) { return 8 * brief_rec_tr(nt) + 32; }
 
 // --- canonical parameter buffer: W0[F,cin] b0[F] | (W_l[F,F] b_l[F]) x (L-2) | Wh[cout,F] bh[cout]
 BL_HD int64_t brief_canon_hidden_off(const brief_siren_desc &d, int l /*1..L-2*/)
@@ -53,7 +56,7 @@ BL_HD int brief_nt(const brief_siren_desc &d)
     const int nt = (d.features + 31) / 32;
     if (d.precision == BRIEF_PREC_BF16) return nt <= 8 ? 8 : 16;     // the bf16 kernels exist for 256 and 512 padded features
     if (d.precision == BRIEF_PREC_BF16X3) return 8;                  // split precision: one kernel set, 256 padded features (check_desc: F <= 256)
-    return nt <= 8 ? nt : (nt <= 12 ? 12 : 16);
+    return nt <= 8 ? nt : (nt <= 12 ? 12 : (nt <= 16 ? 16 : nt));      // above 512 features: k_lean walks a run-time number of tiles
 }
 BL_HD int64_t brief_pk_w0(const brief_siren_desc &) { return 0; }
 BL_HD int64_t brief_pk_hidden_stride(const brief_siren_desc &d)

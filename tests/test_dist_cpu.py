@@ -133,3 +133,29 @@ def test_three_rank_z_sharded_evaluation():
         assert nblocks == 5                                        # every rank got rank 0's block list (3 x 2 x 1 blocks of the ragged split, minus the dropped one)
         assert tot[0] == sse_full and tot[2] == nz and tot[3] == size
         assert abs(tot[1] - ss_full) < 1e-9
+
+
+def test_eight_rank_z_sharded_evaluation_and_lpt():
+    """the rank count of the SCALE run (8) on the CPU: the same collective pattern with 13 slices over 8 ranks (slabs of one or two
+    slices), and the LPT assignment of a DivideTask's blocks to 8 ranks (C4: eight equal octants -> one each; C5-like mixes)"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_eval, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(8)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == list(range(8))
+    for rank, tot, sse_full, ss_full, nz, size, nblocks in res:
+        assert nblocks == 5 and tot[0] == sse_full and tot[2] == nz and tot[3] == size and abs(tot[1] - ss_full) < 1e-9
+    assert sorted(assign_blocks([1.0] * 8, 8)) == list(range(8))
+    mixed = [64.0] * 2 + [8.0] * 16 + [1.0] * 64                    # two large blocks, many small ones: 320 units over 8 ranks
+    own = assign_blocks(mixed, 8)
+    loads = [sum(c for c, o in zip(mixed, own) if o == r) for r in range(8)]
+    assert max(loads) == 64.0 and min(loads) >= 30.0 and set(own) == set(range(8))

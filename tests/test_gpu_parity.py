@@ -70,7 +70,13 @@ def _check_grads(m, d, grads_ref, tol=1e-4, grads_ref64=None):
     mw, mb = O.unpack_params(d, m.grads.cpu().numpy())
     if grads_ref64 is not None:
         w64, b64 = O.unpack_params(d, grads_ref64)
-        tol = max(tol, 3.0 * max(max(relerr(gw[l], w64[l]), relerr(gb[l], b64[l])) for l in range(d.layers)))
+        own = max(max(relerr(gw[l], w64[l]), relerr(gb[l], b64[l])) for l in range(d.layers))
+        if 3.0 * own > tol:
+            worst = max(max(relerr(mw[l], gw[l]), relerr(mb[l], gb[l])) for l in range(d.layers))
+            # visible with pytest -s / -rP: how often, and by how much, the band is widened (round-3 verdict)
+            print("_check_grads: band widened from %.1e to %.1e for layers=%d features=%d (oracle f32 vs f64: %.1e; HIP vs oracle f32: %.1e)" %
+                  (tol, 3.0 * own, d.layers, d.features, own, worst))
+        tol = max(tol, 3.0 * own)
     for l in range(d.layers):
         assert relerr(mw[l], gw[l]) < tol, ("weight", l)
         assert relerr(mb[l], gb[l]) < tol, ("bias", l)
@@ -427,7 +433,7 @@ def test_sample_indices_and_sse():
 
 def test_errors_are_loud():
     L = _lib.lib()
-    d = _lib.SirenDesc(3, 1, 5, 600, 20.0, 30.0, 0, 0)
+    d = _lib.SirenDesc(3, 1, 5, 1100, 20.0, 30.0, 0, 0)
     assert L.brief_packed_count(C.byref(d)) == -1
     m, _, _ = make_net(3, 16, 20.0)
     with pytest.raises(_lib.BriefError):

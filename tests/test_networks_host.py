@@ -75,8 +75,16 @@ def test_capi_exports_and_sizes():
     wide = _lib.SirenDesc(3, 1, 9, 512, 20.0, 30.0, 0, 0)
     assert L.brief_param_count(C.byref(wide)) == 1841153          # BASELINE config 3 network (8x512)
     assert L.brief_packed_count(C.byref(_lib.SirenDesc(3, 1, 5, 300, 20.0, 30.0, 0, 0))) == 384 * 4 + 3 * (2 * 384 * 384 + 384) + 4 * 384 + 4
-    bad = _lib.SirenDesc(3, 1, 5, 513, 20.0, 30.0, 0, 0)
+    # above 512 features the tile count is exact (k_lean walks a run-time number of tiles): the shipped default.yaml on a 512^3
+    # uint16 volume solves to F = 527 = 17 tiles (utils/Networks.py:299-314 has no width limit)
+    w527 = _lib.SirenDesc(3, 1, 5, 527, 20.0, 30.0, 0, 0)
+    assert L.brief_param_count(C.byref(w527)) == 527 * 3 + 527 + 3 * (527 * 527 + 527) + 527 + 1
+    assert L.brief_packed_count(C.byref(w527)) == 544 * 4 + 3 * (2 * 544 * 544 + 544) + 4 * 544 + 4
+    assert L.brief_packed_count(C.byref(_lib.SirenDesc(3, 1, 5, 1024, 20.0, 30.0, 0, 0))) == 1024 * 4 + 3 * (2 * 1024 * 1024 + 1024) + 4 * 1024 + 4
+    assert L.brief_train_workspace_bytes(C.byref(w527), 100000) > 6 * 544 * 100000 * 4
+    bad = _lib.SirenDesc(3, 1, 5, 1025, 20.0, 30.0, 0, 0)
     assert L.brief_param_count(C.byref(bad)) == -1 and b"features" in L.brief_last_error()
+    assert L.brief_param_count(C.byref(_lib.SirenDesc(3, 1, 5, 513, 20.0, 30.0, 0, 1))) == -1 and b"BF16" in L.brief_last_error()
 
 
 def test_every_function_the_header_declares_is_exported():
