@@ -2889,7 +2889,7 @@ static const int g_reduce_sg_small = env_int("BRIEF_REDUCE_SG", 0, 0, 64);      
 // samples one workgroup tile covers: 32 per sample sub-tile; the split-precision TRAIN kernel walks 64-sample tiles
 static int64_t fused_wg_samples(const brief_siren_desc &d, bool train)
 {
-    if (brief_nt(d) > 16) return 32;                                                                  // k_lean<1, ...>: one 32-sample tile
+    if (brief_nt(d) >= BRIEF_LEAN_FROM) return 32;                                                    // k_lean<1, ...>: one 32-sample tile
     if (!train && d.precision == BRIEF_PREC_F32) return 32 * (4 / brief_wm_infer(brief_nt(d)));      // KCfg<NT, true>
     return brief_wg_samples(brief_nt(d));      // (the split-precision TRAIN kernel deals 32-sample half-tiles too, and walks them in pairs)
 }
@@ -2901,7 +2901,9 @@ static int fused_grid(const brief_siren_desc &d, int64_t n, bool train)
     // resident workgroups per CU = what the kernel's launch bounds were compiled for (BRIEF_WG_PER_CU: diagnostics)
     const int wpe = g_wg_per_cu_set ? g_wg_per_cu : (d.precision == BRIEF_PREC_BF16X3 && (train || g_x3_decode) ? 2 /* k_fused_x3 */ :
                     (BRIEF_FUSED64 && train && nt == 8 ? 2 /* k_lean<2, 2, 8> */ : (train ? fused_train_wpe(nt) : (nt > 8 ? 2 : 3))));
-    const int64_t cap = (int64_t)kCUs * ((train && nt > 8) || nt > 16 ? 1 : wpe);      // TRAIN > 8 tiles: 512-register kernel, one workgroup per CU; > 16 tiles: the image fills the CU's LDS
+    int64_t cap = (int64_t)kCUs * (train && nt > 8 ? 1 : wpe);      // TRAIN > 8 tiles: 512-register kernel, one workgroup per CU
+    if (nt >= BRIEF_LEAN_FROM)      // k_lean: what its launch bounds and its LDS image allow
+        cap = (int64_t)kCUs * (lean_wpe(1, (nt + 3) / 4) == 2 && 2 * sizeof(float) * lean_lds(1, (nt + 3) / 4, nt).total <= 160 * 1024 ? 2 : 1);
     return (int)(tiles < cap ? (tiles > 0 ? tiles : 1) : cap);
 }
 // k_fused<TRAIN> launch plan: a persistent body of `cap` workgroups over whole rounds of tiles, the rest of the batch
@@ -3118,8 +3120,10 @@ static int launch_fused(const FusedArgs &fa, int grid, hipStream_t st)
         return 0;
     }
 #endif
-    if (nt > 16) {
-        // above 512 features: k_lean<1, MTW, 0>, a run-time number of feature tiles, MTW = ceil(nt / 4) of them per wave
+    if (nt >= BRIEF_LEAN_FROM && (TRAIN || (nt != 12 && nt != 16))) {
+        // above 256 features: k_lean<1, MTW, 0>, a run-time number of feature tiles, MTW = ceil(nt / 4) of them per wave.  (Inference of
+        // exactly 12 or 16 tiles stays on k_fused<12 / 16, false>, whose unrolled chains decode 5 % faster: 4x384 0.89 against 0.84 of the
+        // fp32 peak, 4x512 0.92 against 0.87 — tools/decode_widths.py; the layouts are the same.)
         const int mtw = (nt + 3) / 4;
         const size_t lds = sizeof(float) * lean_lds(1, mtw, nt).total;
         static bool attr_w[9] = {};
@@ -3134,6 +3138,9 @@ static int launch_fused(const FusedArgs &fa, int grid, hipStream_t st)
         break;                                                                                           \
     }
         switch (mtw) {
+#if BRIEF_LEAN_FROM < 17
+            BRIEF_WIDE(3) BRIEF_WIDE(4)      // 257 .. 512 features
+#endif
             BRIEF_WIDE(5) BRIEF_WIDE(6) BRIEF_WIDE(7) BRIEF_WIDE(8)
         default: return fail(BRIEF_ERR_INVALID, "unsupported width");
         }
@@ -3143,7 +3150,16 @@ static int launch_fused(const FusedArgs &fa, int grid, hipStream_t st)
     }
     switch (nt) {
         BRIEF_CASE(1) BRIEF_CASE(2) BRIEF_CASE(3) BRIEF_CASE(4)
-        BRIEF_CASE(5) BRIEF_CASE(6) BRIEF_CASE(7) BRIEF_CASE(8) BRIEF_CASE(12) BRIEF_CASE(16)
+        BRIEF_CASE(5) BRIEF_CASE(6) BRIEF_CASE(7) BRIEF_CASE(8)
+    case 12:
+    case 16:
+        if constexpr (!TRAIN || BRIEF_LEAN_FROM > 16) {      // (the TRAIN kernels of these widths exist only in a -DBRIEF_LEAN_FROM=17 build)
+            const size_t lds12 = sizeof(float) * FusedLds<12, !TRAIN>::TOTAL, lds16 = sizeof(float) * FusedLds<16, !TRAIN>::TOTAL;
+            if (nt == 12) hipLaunchKernelGGL((k_fused<12, TRAIN>), dim3(grid), dim3(256), lds12, st, fa);
+            else hipLaunchKernelGGL((k_fused<16, TRAIN>), dim3(grid), dim3(256), lds16, st, fa);
+            break;
+        }
+        return fail(BRIEF_ERR_INVALID, "unsupported width");
     default: return fail(BRIEF_ERR_INVALID, "unsupported width");
     }
 #undef BRIEF_CASE
@@ -3415,10 +3431,13 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
     case NTV:                                                                                              \
         hipLaunchKernelGGL((k_wgrad<NTV>), dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(NTV), st, wa); \
         break;
-        if (nt > 16) {
+        if (nt >= BRIEF_LEAN_FROM) {
             // run-time width: ceil(nt / 8) quadrants per side of QT = ceil(nt / quadrants) tiles (the last row / column may be short)
             const int qt = (nt + wgrad_nq(nt) - 1) / wgrad_nq(nt);
             switch (qt) {
+#if BRIEF_LEAN_FROM < 17
+            case 5: hipLaunchKernelGGL((k_wgrad<0, 5>), dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(5), st, wa); break;
+#endif
             case 6: hipLaunchKernelGGL((k_wgrad<0, 6>), dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(6), st, wa); break;
             case 7: hipLaunchKernelGGL((k_wgrad<0, 7>), dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(7), st, wa); break;
             case 8: hipLaunchKernelGGL((k_wgrad<0, 8>), dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(8), st, wa); break;
@@ -3427,7 +3446,10 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
         } else
         switch (nt) {
             BRIEF_CASE(1) BRIEF_CASE(2) BRIEF_CASE(3) BRIEF_CASE(4)
-            BRIEF_CASE(5) BRIEF_CASE(6) BRIEF_CASE(7) BRIEF_CASE(8) BRIEF_CASE(12) BRIEF_CASE(16)
+            BRIEF_CASE(5) BRIEF_CASE(6) BRIEF_CASE(7) BRIEF_CASE(8)
+#if BRIEF_LEAN_FROM > 16
+            BRIEF_CASE(12) BRIEF_CASE(16)
+#endif
         }
 #undef BRIEF_CASE
         HIP_TRY(hipGetLastError());

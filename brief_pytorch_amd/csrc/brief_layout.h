@@ -10,7 +10,7 @@
 #define BL_HD static inline
 #endif
 
-#define BRIEF_MAX_NT 32         // features <= 1024 (257 .. 512 are padded to 384 or 512 features; above 512 the tile count is exact)
+#define BRIEF_MAX_NT 32         // features <= 1024; the width is padded to whole 32-feature tiles only
 // per-wave partial record of the fused kernels: dW0[TR local features][4] | dWh[4][TR] | dbh[4] | loss | stamps, TR = 128 local
 // features per wave (4 feature tiles) up to 512 features, 256 (8 tiles) above: brief_rec_tr.  The constants are the TR = 128 case.
 #define BRIEF_REC_FLOATS 1056
@@ -51,12 +51,19 @@ BL_HD int64_t brief_canon_count(const brief_siren_desc &d)
 //   (lane = 32*hi + i ; this is the operand order of v_mfma_f32_32x32x2_f32, see brief_hip.hip)
 // number of 32-feature tiles the width is padded to: exact up to 8 tiles, then 12 or 16 (only those
 // kernel instantiations exist above 256 features)
+// First tile count that runs on k_lean with an exact run-time width.  9 (round 4): every width above 256 features — 4x320 trains at
+// 0.57 of the fp32 peak instead of 0.48 as a padded 384-wide net on k_fused<12>, 4x448 at 0.66 instead of 0.61, and the exact 12- and 16-tile
+// widths gain too (0.70 / 0.78 against 0.67 / 0.77: two 256-register workgroups per CU instead of one of 512).  17 restores round 3's
+// padding of 257 .. 512 features to 384 / 512 (k_fused<12 / 16>, k_wgrad<12 / 16>).
+#ifndef BRIEF_LEAN_FROM
+#define BRIEF_LEAN_FROM 9
+#endif
 BL_HD int brief_nt(const brief_siren_desc &d)
 {
     const int nt = (d.features + 31) / 32;
     if (d.precision == BRIEF_PREC_BF16) return nt <= 8 ? 8 : 16;     // the bf16 kernels exist for 256 and 512 padded features
     if (d.precision == BRIEF_PREC_BF16X3) return 8;                  // split precision: one kernel set, 256 padded features (check_desc: F <= 256)
-    return nt <= 8 ? nt : (nt <= 12 ? 12 : (nt <= 16 ? 16 : nt));      // above 512 features: k_lean walks a run-time number of tiles
+    return nt <= 8 || nt >= BRIEF_LEAN_FROM ? nt : (nt <= 12 ? 12 : 16);      // k_lean walks a run-time number of tiles
 }
 BL_HD int64_t brief_pk_w0(const brief_siren_desc &) { return 0; }
 BL_HD int64_t brief_pk_hidden_stride(const brief_siren_desc &d)

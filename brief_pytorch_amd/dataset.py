@@ -38,9 +38,8 @@ def create_flattened_coords(coords_shape, mode="n11"):
 def reconstruct_flattened(data_shape, sample_size, sample_nf, device="cpu", half=False, coords_mode="-1,1"):
     """utils/misc.py:59-92: evaluate `sample_nf` over the whole grid in chunks of `sample_size` coordinates and
     reshape to data_shape.  Kept for code written against the reference; NFGR.decompress uses SIREN.decode_grid
-    (one launch, coordinates synthesised in-kernel) instead."""
-    if half:
-        raise NotImplementedError("fp16 decode is not available on the fused path")
+    (one launch, coordinates synthesised in-kernel) instead.  half=True follows the reference's fp16 decode (main.py:287-288):
+    fp16 coordinates and an fp16 result; the module is then expected to be in its low-precision mode (SIREN.half())."""
     *coords_shape, data_channel = data_shape
     if len(coords_shape) not in (2, 3):
         raise NotImplementedError
@@ -48,7 +47,12 @@ def reconstruct_flattened(data_shape, sample_size, sample_nf, device="cpu", half
         coords = create_flattened_coords(tuple(coords_shape), coords_mode).to(device)
         pop = coords.shape[0]
         out = torch.zeros((pop, data_channel), device=device)
+        if half:
+            out = out.half()            # utils/misc.py:70-71, 78-79: an fp16 result, fp16 coordinates into the (half) module
         for i in range(math.ceil(pop / sample_size)):
             a, b = i * sample_size, min((i + 1) * sample_size, pop)
-            out[a:b, :] = sample_nf(coords[a:b, :])
+            sampled = coords[a:b, :]
+            if half:
+                sampled = sampled.half()
+            out[a:b, :] = sample_nf(sampled)
     return out.reshape(*coords_shape, data_channel)

@@ -202,11 +202,27 @@ class SIREN:
     def cpu(self):
         return self.to("cpu")
 
-    def float(self):
+    def _set_precision(self, precision):
+        if precision != self.precision:
+            self.precision = precision
+            self.desc.precision = _lib.PRECISION[precision]
+            self.packed = None          # the fragment-ordered copy has another size and content
+            self._ws = None
+            self._stale = True
         return self
 
+    def float(self):
+        """nn.Module.float() as the reference's low-precision loop uses it (main.py:398: back to fp32 for the update)"""
+        return self._set_precision(getattr(self, "_float_precision", self.precision))
+
     def half(self):
-        raise NotImplementedError("fp16 mode (Compress.half) is not available on the fused fp32 path")
+        """nn.Module.half() as the reference uses it (main.py:212, 287-288, 389): its fp16 mode.  The MI355X counterpart is the
+        bf16 matrix pipe with fp32 master weights (BRIEF_PREC_BF16, what Compress.half selects in NFGR): the parameters stay
+        fp32, the hidden GEMMs of forward / backward / decode run on v_mfma_f32_32x32x16_bf16.  Widths above 512 have no bf16
+        kernels and stay exact."""
+        if self.precision != "bf16":
+            self._float_precision = self.precision
+        return self._set_precision("bf16" if self.features <= 512 else self.precision)
 
     def eval(self):
         return self

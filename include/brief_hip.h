@@ -22,7 +22,7 @@ extern "C" {
 
 typedef enum {
     BRIEF_OK = 0,
-    BRIEF_ERR_INVALID = -1,      /* bad argument / unsupported configuration (e.g. res=True, F > 512) */
+    BRIEF_ERR_INVALID = -1,      /* bad argument / unsupported configuration (e.g. res=True, F > 1024) */
     BRIEF_ERR_LAUNCH = -2,       /* HIP launch / runtime error */
     BRIEF_ERR_WORKSPACE = -3     /* workspace too small */
 } brief_status;
@@ -33,7 +33,9 @@ typedef struct {
     int32_t cin;         /* 2 | 3 */
     int32_t cout;        /* 1 .. 4 */
     int32_t layers;      /* >= 2 */
-    int32_t features;    /* 1 .. 512 (padded internally to a multiple of 32 up to 256, then to 384 or 512) */
+    int32_t features;    /* 1 .. 1024 for BRIEF_PREC_F32 (padded internally to whole 32-feature tiles; SIREN.calc_features, utils/Networks.py:299-314,
+                          * has no width limit: the shipped default.yaml on a 512^3 uint16 volume solves to 527), 1 .. 512 for BRIEF_PREC_BF16,
+                          * 1 .. 256 for BRIEF_PREC_BF16X3 */
     float w0_first;
     float w0_hidden;
     int32_t output_act;
@@ -164,11 +166,13 @@ typedef struct brief_fit_job {
  * synchronisation, nothing allocated).  Bit-identical to calling brief_siren_fit_step `steps` times. */
 int brief_siren_fit(const brief_fit_job *job, int64_t steps, void *stream);
 
-/* Grouped independent fits (the per-block loop of main.py:547-575 for the blocks one GPU owns): job j runs on
- * an internal HIP stream j mod 8, forked from and joined back into `stream` with events, so that kernels of
- * different blocks overlap (narrow nets leave most of the 256 CUs idle between their launches).  Each job's
- * results are bit-identical to brief_siren_fit on its own; jobs must not share any buffer except read-only
- * targets/weights.  Call from one host thread per process (one process per GPU). */
+/* Grouped independent fits (the per-block loop of main.py:547-575 for the blocks one GPU owns).  Narrow nets (features <= 64:
+ * what BRIEF's own YAMLs produce) of one kernel variant are trained by ONE launch pair per step for up to 64 jobs (k_small_group +
+ * k_reduce_group: workgroup ranges per job, the jobs' static arguments in a device table inside the first job's workspace) — the
+ * many small blocks of a DivideTask no longer cost a launch pair per block and step; every other job runs its own launches.  Units
+ * (groups and single jobs) run on internal HIP streams, unit u on stream u mod 8, forked from and joined back into `stream` with
+ * events, so that kernels of different units overlap.  Each job's results are bit-identical to brief_siren_fit on its own; jobs
+ * must not share any buffer except read-only targets/weights.  Call from one host thread per process (one process per GPU). */
 int brief_multi_fit(const brief_fit_job *jobs, int32_t njobs, int64_t steps, void *stream);
 
 /* optimizer.step() of main.py:399 (torch.optim.Adamax/Adam/SGD single-tensor rules); t is the

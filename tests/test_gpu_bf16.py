@@ -238,3 +238,20 @@ def test_bf16_end_of_fit_against_the_reference_low_precision_band(golden):
     e200 = float(np.max(np.abs(losses[:200] - g["f32_losses"][:200]) / g["f32_losses"][:200]))
     print("bf16 loss trace vs the reference's fp32 trace through step 200: %.2e" % e200)
     assert e200 < 2e-2
+
+
+def test_half_surface_of_the_reference_decodes_through_the_low_precision_mode():
+    """module.half() + reconstruct_flattened(..., half=True) (main.py:287-288, utils/misc.py:59-92): the reference's fp16 decode on
+    this module — fp16 coordinates in, fp16 volume out, hidden GEMMs on the bf16 pipe — stays within the low-precision band of the
+    fp32 decode of the same parameters, and .float() restores the exact path bit for bit."""
+    from brief_pytorch_amd.dataset import reconstruct_flattened
+    torch.manual_seed(4)
+    m = SIREN(features=96, layers=4, w0=20).to(DEV)
+    shape = (6, 10, 12, 1)
+    exact = reconstruct_flattened(shape, 500, m.forward, device=DEV)
+    again = m.decode_grid(shape[:3]).view(*shape)
+    assert torch.equal(exact, again)
+    low = reconstruct_flattened(shape, 500, m.half().forward, device=DEV, half=True)
+    assert low.dtype == torch.float16 and low.shape == exact.shape and m.precision == "bf16"
+    assert rel(low.float(), exact) < 3e-2 and not torch.equal(low.float(), exact)
+    assert torch.equal(reconstruct_flattened(shape, 500, m.float().forward, device=DEV), exact) and m.precision == "fp32"

@@ -133,6 +133,15 @@ def test_reconstruct_flattened_chunks():
     out = reconstruct_flattened((3, 4, 5, 1), 16, nf, coords_mode="-1,1")
     assert calls == [16, 16, 16, 12] and out.shape == (3, 4, 5, 1)
     assert torch.equal(out.reshape(-1, 1), create_flattened_coords((3, 4, 5), "-1,1").sum(-1, keepdim=True))
+    # half=True (utils/misc.py:70-71, 78-79, 85-86): fp16 coordinates go in, an fp16 volume comes out
+    seen = []
+
+    def nf16(c):
+        seen.append(c.dtype)
+        return c.float().sum(-1, keepdim=True)
+    out16 = reconstruct_flattened((3, 4, 5, 1), 16, nf16, half=True, coords_mode="-1,1")
+    assert out16.dtype == torch.float16 and set(seen) == {torch.float16}
+    assert torch.equal(out16.reshape(-1, 1), create_flattened_coords((3, 4, 5), "-1,1").half().float().sum(-1, keepdim=True).half())
 
 
 def test_configure_optimizer_and_scheduler_mirror():

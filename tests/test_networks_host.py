@@ -58,6 +58,12 @@ def test_module_surface():
         SIREN(res=True)
     with pytest.raises(_lib.BriefError):           # no CPU fallback
         m.forward(torch.zeros(4, 3))
+    # .half() / .float() (main.py:212, 287-288, 389, 398): the low-precision mode and back; parameters stay fp32 masters
+    p0 = m.params.clone()
+    assert m.half() is m and m.precision == "bf16" and m.desc.precision == _lib.PRECISION["bf16"] and m.params.dtype == torch.float32
+    assert m.float() is m and m.precision == "fp32" and m.desc.precision == 0 and torch.equal(m.params, p0)
+    wide = SIREN(features=600, layers=3)
+    assert wide.half().precision == "fp32"          # no bf16 kernels above 512 features: stays exact
 
 
 def test_capi_exports_and_sizes():
@@ -74,7 +80,7 @@ def test_capi_exports_and_sizes():
     assert L.brief_train_workspace_bytes(C.byref(d), 100000) > 6 * 256 * 100000 * 4
     wide = _lib.SirenDesc(3, 1, 9, 512, 20.0, 30.0, 0, 0)
     assert L.brief_param_count(C.byref(wide)) == 1841153          # BASELINE config 3 network (8x512)
-    assert L.brief_packed_count(C.byref(_lib.SirenDesc(3, 1, 5, 300, 20.0, 30.0, 0, 0))) == 384 * 4 + 3 * (2 * 384 * 384 + 384) + 4 * 384 + 4
+    assert L.brief_packed_count(C.byref(_lib.SirenDesc(3, 1, 5, 300, 20.0, 30.0, 0, 0))) == 320 * 4 + 3 * (2 * 320 * 320 + 320) + 4 * 320 + 4      # whole 32-feature tiles (round 3: 384)
     # above 512 features the tile count is exact (k_lean walks a run-time number of tiles): the shipped default.yaml on a 512^3
     # uint16 volume solves to F = 527 = 17 tiles (utils/Networks.py:299-314 has no width limit)
     w527 = _lib.SirenDesc(3, 1, 5, 527, 20.0, 30.0, 0, 0)

@@ -19,8 +19,13 @@ def bench(tag, shapes, steps=400):
     torch.cuda.synchronize(); t0 = time.time()
     mf.run(steps)
     torch.cuda.synchronize(); t_multi = time.time() - t0
-    print("%-44s sequential %.3f s   co-trained %.3f s   x%.2f" % (tag, t_seq, t_multi, t_seq / t_multi), flush=True)
+    nb = len(shapes)
+    print("%-44s sequential %.3f s   co-trained %.3f s   x%.2f   (%.1f us per block-step co-trained, %.1f sequential)" %
+          (tag, t_seq, t_multi, t_seq / t_multi, t_multi / steps / nb * 1e6, t_seq / steps / nb * 1e6), flush=True)
 bench("8 x (5x22, 32^3 full batch)", [(5, 22, (32, 32, 32), 'full', 0)] * 8)
+bench("8 x (6x22, 32^3 full batch)", [(6, 22, (32, 32, 32), 'full', 0)] * 8)
+bench("64 x (5x22, 16^3 full batch)", [(5, 22, (16, 16, 16), 'full', 0)] * 64, steps=200)
+bench("1 x (5x22, 64^3 full batch)", [(5, 22, (64, 64, 64), 'full', 0)] * 1)
 bench("8 x (5x35, 64^3 full batch)", [(5, 35, (64, 64, 64), 'full', 0)] * 8)
 bench("8 x (5x35, 128^3, 100k samples)", [(5, 35, (128, 128, 128), 'randompoint', 100000)] * 8)
 bench("4 x (7x56, 32x256x256, 100k samples)", [(7, 56, (32, 256, 256), 'randompoint', 100000)] * 4)
