@@ -30,6 +30,7 @@
 //   brief_bf16.inc     k16 / k_wgrad16 / k_reduce16: the same path on v_mfma_f32_32x32x16_bf16 (BRIEF_PREC_BF16).
 //   k_sample, k_sse_u16, k_ssim_u16, k_deblock_edge: index stream, metrics and the deblocking filter.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -1892,6 +1893,16 @@ struct SmallGroupArgs {
     uint64_t rng_step[BRIEF_GROUP_MAX];
     const int64_t *idx[BRIEF_GROUP_MAX];
 };
+// dst = *src, with src read through the constant address space (dword by dword: scalar loads, the copy dissolves into SGPRs)
+template <typename T>
+__device__ __forceinline__ void const_copy(T &dst, const T *src)
+{
+    static_assert(sizeof(T) % 4 == 0, "dword-sized arguments");
+    const __attribute__((address_space(4))) uint32_t *s4 = (const __attribute__((address_space(4))) uint32_t *)src;
+    uint32_t *d4 = reinterpret_cast<uint32_t *>(&dst);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(T) / 4); ++i) d4[i] = s4[i];
+}
 __device__ __forceinline__ int group_job(const int *begin, int njobs, int b)
 {
     int j = 0;
@@ -1903,8 +1914,14 @@ __global__ __launch_bounds__(256, small_wpe(HB)) void k_small_group(const SmallG
 {
     const int b = (int)blockIdx.x;
     const int j = group_job(g.wg_begin, g.njobs, b);
-    const FusedArgs *tp = g.table + j;
-    small_body<NT, HB>(*tp, tp, g.idx[j], g.rng_step[j], b - g.wg_begin[j], g.wg_begin[j + 1] - g.wg_begin[j]);
+    // the table entry is read through the CONSTANT address space (written by an earlier launch, never during this one): scalar loads
+    // into SGPRs exactly like kernel arguments.  As plain global memory every use of an argument inside the tile loop was a vector
+    // load + v_readfirstlane behind a wait (the kernel stores through pointers it loaded from the same table, so nothing could be
+    // hoisted): 197 us per 64^3 job of a 4x35 net in a group of eight against 150 us on its own.
+    kargs_t tp = (kargs_t)(g.table + j);
+    FusedArgs a;
+    const_copy(a, g.table + j);
+    small_body<NT, HB>(a, tp, g.idx[j], g.rng_step[j], b - g.wg_begin[j], g.wg_begin[j + 1] - g.wg_begin[j]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2570,7 +2587,9 @@ __global__ __launch_bounds__(1024) void k_reduce_group(const ReduceGroupArgs g)
 {
     const int b = (int)blockIdx.x;
     const int j = group_job(g.blk_begin, g.njobs, b);
-    reduce_body(g.table[j], g.opt[j], g.loss_out[j], g.nb_hidden[j], b - g.blk_begin[j]);
+    ReduceArgs a;
+    const_copy(a, g.table + j);      // (constant address space: see k_small_group)
+    reduce_body(a, g.opt[j], g.loss_out[j], g.nb_hidden[j], b - g.blk_begin[j]);
 }
 
 #include "brief_bf16.inc"
@@ -2900,7 +2919,7 @@ static int fused_grid(const brief_siren_desc &d, int64_t n, bool train)
     const int64_t tiles = (n + wgs_ - 1) / wgs_;
     // resident workgroups per CU = what the kernel's launch bounds were compiled for (BRIEF_WG_PER_CU: diagnostics)
     const int wpe = g_wg_per_cu_set ? g_wg_per_cu : (d.precision == BRIEF_PREC_BF16X3 && (train || g_x3_decode) ? 2 /* k_fused_x3 */ :
-                    (BRIEF_FUSED64 && train && nt == 8 ? 2 /* k_lean<2, 2, 8> */ : (train ? fused_train_wpe(nt) : (nt > 8 ? 2 : 3))));
+                    (BRIEF_FUSED64 && train && nt == 8 ? (BRIEF_FUSED64 == 1 ? 2 : 3) /* k_lean<2, 2, 8> / k_lean<1, 2, 8> */ : (train ? fused_train_wpe(nt) : (nt > 8 ? 2 : 3))));
     int64_t cap = (int64_t)kCUs * (train && nt > 8 ? 1 : wpe);      // TRAIN > 8 tiles: 512-register kernel, one workgroup per CU
     if (nt >= BRIEF_LEAN_FROM)      // k_lean: what its launch bounds and its LDS image allow
         cap = (int64_t)kCUs * (lean_wpe(1, (nt + 3) / 4) == 2 && 2 * sizeof(float) * lean_lds(1, (nt + 3) / 4, nt).total <= 160 * 1024 ? 2 : 1);
@@ -3084,8 +3103,18 @@ static void fill_grid(GridArgs &g, const brief_grid_desc *grid)
     g.fast = total < 4294967296.0;
 }
 
+// One launch, optionally with a start / stop event pair bound to the DISPATCH itself (hipExtLaunchKernel: the timestamps are the
+// kernel's own begin and end): the live timing of the dominant kernel (brief_profile_*) then costs no marker packets on the stream
+// — with hipEventRecord around the launch every step carried two barrier packets, 1.8 % of the headline step.
+template <typename KP, typename A>
+static inline void launch_timed(KP kern, int grid, int block, size_t lds, hipStream_t st, const A &arg, hipEvent_t e0, hipEvent_t e1)
+{
+    if (e0) hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), (uint32_t)lds, st, e0, e1, 0, arg);
+    else hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, st, arg);
+}
+
 template <bool TRAIN>
-static int launch_fused(const FusedArgs &fa, int grid, hipStream_t st)
+static int launch_fused(const FusedArgs &fa, int grid, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr)
 {
     const int nt = brief_nt(fa.d);
     if (fa.d.precision == BRIEF_PREC_BF16X3 && (TRAIN || g_x3_decode)) {
@@ -3096,26 +3125,28 @@ static int launch_fused(const FusedArgs &fa, int grid, hipStream_t st)
             HIP_TRY(hipFuncSetAttribute((const void *)k_fused_x3<TRAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr_t64 = true;
         }
-        hipLaunchKernelGGL(k_fused_x3<TRAIN>, dim3(grid), dim3(256), lds, st, fa);
+        launch_timed(k_fused_x3<TRAIN>, grid, 256, lds, st, fa, e0, e1);
         HIP_TRY(hipGetLastError());
         return 0;
     }
 #define BRIEF_CASE(NTV)                                                                                  \
     case NTV: {                                                                                          \
         const size_t lds = sizeof(float) * FusedLds<NTV, !TRAIN>::TOTAL;                                 \
-        hipLaunchKernelGGL((k_fused<NTV, TRAIN>), dim3(grid), dim3(256), lds, st, fa);                   \
+        launch_timed(k_fused<NTV, TRAIN>, grid, 256, lds, st, fa, e0, e1);                               \
         break;                                                                                           \
     }
 #if BRIEF_FUSED64
     if (nt == 8 && TRAIN) {
-        // 64-sample tiles for the 8-tile TRAIN kernel (k_lean<2, 2, 8>: every weight fragment against two sample halves)
-        const size_t lds = sizeof(float) * lean_lds(2, 2, 8).total;
+        // experiments on the 8-tile TRAIN step: 1 = 64-sample tiles (k_lean<2, 2, 8>: every weight fragment against two sample halves);
+        // 2 = k_lean's one-state-array skeleton on 32-sample tiles, three workgroups per CU (k_lean<1, 2, 8>)
+        constexpr int SHV = BRIEF_FUSED64 == 1 ? 2 : 1;
+        const size_t lds = sizeof(float) * lean_lds(SHV, 2, 8).total;
         static bool attr_64 = false;
         if (!attr_64) {
-            HIP_TRY(hipFuncSetAttribute((const void *)k_lean<2, 2, 8, TRAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIP_TRY(hipFuncSetAttribute((const void *)k_lean<SHV, 2, 8, TRAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr_64 = true;
         }
-        hipLaunchKernelGGL((k_lean<2, 2, 8, TRAIN>), dim3(grid), dim3(256), lds, st, fa);
+        launch_timed(k_lean<SHV, 2, 8, TRAIN>, grid, 256, lds, st, fa, e0, e1);
         HIP_TRY(hipGetLastError());
         return 0;
     }
@@ -3134,7 +3165,7 @@ static int launch_fused(const FusedArgs &fa, int grid, hipStream_t st)
                                         (int)(sizeof(float) * lean_lds(1, MTWV, 4 * MTWV).total)));      \
             attr_w[MTWV] = true;                                                                         \
         }                                                                                                \
-        hipLaunchKernelGGL((k_lean<1, MTWV, 0, TRAIN>), dim3(grid), dim3(256), lds, st, fa);             \
+        launch_timed(k_lean<1, MTWV, 0, TRAIN>, grid, 256, lds, st, fa, e0, e1);                         \
         break;                                                                                           \
     }
         switch (mtw) {
@@ -3155,8 +3186,8 @@ static int launch_fused(const FusedArgs &fa, int grid, hipStream_t st)
     case 16:
         if constexpr (!TRAIN || BRIEF_LEAN_FROM > 16) {      // (the TRAIN kernels of these widths exist only in a -DBRIEF_LEAN_FROM=17 build)
             const size_t lds12 = sizeof(float) * FusedLds<12, !TRAIN>::TOTAL, lds16 = sizeof(float) * FusedLds<16, !TRAIN>::TOTAL;
-            if (nt == 12) hipLaunchKernelGGL((k_fused<12, TRAIN>), dim3(grid), dim3(256), lds12, st, fa);
-            else hipLaunchKernelGGL((k_fused<16, TRAIN>), dim3(grid), dim3(256), lds16, st, fa);
+            if (nt == 12) launch_timed(k_fused<12, TRAIN>, grid, 256, lds12, st, fa, e0, e1);
+            else launch_timed(k_fused<16, TRAIN>, grid, 256, lds16, st, fa, e0, e1);
             break;
         }
         return fail(BRIEF_ERR_INVALID, "unsupported width");
@@ -3404,18 +3435,18 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
         return 0;
     }
     const bool prof = g_prof_on && g_prof_n < kProfSlots;
-    if (prof) HIP_TRY(hipEventRecord(g_prof_ev[2 * g_prof_n], st));
+    hipEvent_t pe0 = prof ? g_prof_ev[2 * g_prof_n] : nullptr, pe1 = prof ? g_prof_ev[2 * g_prof_n + 1] : nullptr;
     if (small) {
         const int hb = small_hb(*d);
 #define BRIEF_CASE(NTV, HBV)                                                                                        \
     if (nt == NTV && hb == HBV)                                                                                     \
-        hipLaunchKernelGGL((k_small<NTV, HBV>), dim3(grid1), dim3(256), sizeof(float) * SmallLds<NTV>::TOTAL, st, fa);
+        launch_timed(k_small<NTV, HBV>, grid1, 256, sizeof(float) * SmallLds<NTV>::TOTAL, st, fa, pe0, pe1);
         BRIEF_CASE(1, 1) BRIEF_CASE(1, 3) BRIEF_CASE(1, 5) BRIEF_CASE(1, 7)
         BRIEF_CASE(2, 1) BRIEF_CASE(2, 3) BRIEF_CASE(2, 5) BRIEF_CASE(2, 7)
 #undef BRIEF_CASE
         HIP_TRY(hipGetLastError());
-    } else if (int rc = launch_fused<true>(fa, grid1, st)) return rc;
-    if (prof) { HIP_TRY(hipEventRecord(g_prof_ev[2 * g_prof_n + 1], st)); ++g_prof_n; }
+    } else if (int rc = launch_fused<true>(fa, grid1, st, pe0, pe1)) return rc;
+    if (prof) ++g_prof_n;
 
     if (!small && nsplit > 0) {
         WgradArgs wa;
