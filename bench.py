@@ -274,7 +274,7 @@ def launch_ranks(args):
     import socket
     import subprocess
     shared = os.environ.get("BRIEF_DIST_BACKEND", "nccl") == "gloo" and os.environ.get("BRIEF_SHARE_GPU") == "1"      # rehearsal: ranks share devices
-    if args.gpus > torch.cuda.device_count() and not shared:           # (counting devices does not initialise the GPU)
+    if args.gpus > torch.cuda.device_count() and not shared:           # (the ranks are a CHILD process started below, never an exec of this one)
         sys.stderr.write("bench.py: --gpus %d but only %d device(s) are visible\n" % (args.gpus, torch.cuda.device_count()))
         sys.exit(2)
     sock = socket.socket()

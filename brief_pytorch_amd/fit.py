@@ -123,8 +123,10 @@ class Fitter:
     # indices of a run of steps live on the device as one [steps, n] int64 tensor: at most this many bytes per C-ABI call
     INDEX_STREAM_BYTES = 1 << 28
 
-    def max_steps_per_call(self):
-        return max(1, self.INDEX_STREAM_BYTES // (8 * self.n)) if self.index_stream is not None else 1 << 62
+    def max_steps_per_call(self, share=1):
+        """steps one C-ABI call may cover; `share`: how many fitters with index streams split the budget (MultiFitter: every
+        co-trained block keeps its run of index sets alive until the call returns, so the budget is divided, not multiplied)"""
+        return max(1, self.INDEX_STREAM_BYTES // max(int(share), 1) // (8 * self.n)) if self.index_stream is not None else 1 << 62
 
     def _index_batch(self, t_first, steps):
         """the index sets of steps t_first .. t_first + steps - 1 as one device tensor [steps, n] (draw order = step order,
@@ -222,7 +224,8 @@ class MultiFitter:
             return []
         steps, logs = int(steps), [[] for _ in self.fitters]
         while True:
-            k = min([steps] + [f.max_steps_per_call() for f in self.fitters])
+            share = sum(1 for f in self.fitters if f.index_stream is not None)
+            k = min([steps] + [f.max_steps_per_call(share) for f in self.fitters])
             jobs, lg = zip(*(f.job(k, log) for f in self.fitters))
             arr = (_lib.FitJob * len(jobs))(*jobs)
             _lib.check(_lib.lib().brief_multi_fit(arr, len(jobs), k, _lib.stream_ptr()))

@@ -74,7 +74,7 @@ class NFGR:
         self.Log = Log
         self.args = args
         self.half = bool(opt.Compress.half)
-        # optional key of this build (a reference YAML does not have it): fp32 (default, the parity path) | bf16
+        # optional key of this build (a reference YAML does not have it): fp32 (default, the parity path) | bf16 | bf16x3
         self.precision = str(opt.Compress.get("precision", "fp32"))
         if self.half:
             # Compress.half of the reference (main.py:388-399: fp16 forward/backward, the fp16-rounded weights are what
@@ -96,8 +96,22 @@ class NFGR:
             raise ValueError("There can only be one arg to be used")
         return p.given_size if p.given_size > 0 else os.path.getsize(data_path) / p.filesize_ratio
 
+    #: widest net each optional precision has kernels for (include/brief_hip.h); wider nets run exact fp32
+    PRECISION_MAX_FEATURES = {"bf16": 512, "bf16x3": 256}
+
     def init_module(self):
-        self.module["phi"] = init_phi({**dict(self.opt.Module.phi), "precision": self.precision})
+        precision = self.precision
+        feats = int(self.opt.Module.phi.get("features", 0) or 0)
+        limit = self.PRECISION_MAX_FEATURES.get(precision)
+        if limit is not None and feats > limit:
+            # decided BEFORE any work starts (in a DivideTask one large block would otherwise abort the job after partitioning):
+            # this net runs on the exact fp32 kernels; the artefact records the precision it was fitted in (sideinfos phi_precision)
+            logging.warning("Compress.precision=%s supports at most %d features; this net has %d and runs in fp32" % (precision, limit, feats))
+            precision = "fp32"
+        elif precision == "bf16x3" and 0 < feats < 64:
+            logging.warning("Compress.precision=bf16x3 pads every net to 256 features: a %d-wide net runs ~%dx the work of the fp32 path" % (feats, (256 // max(feats, 1)) ** 2 // 4 or 1))
+        self.module_precision = precision
+        self.module["phi"] = init_phi({**dict(self.opt.Module.phi), "precision": precision})
 
     @staticmethod
     def estimate_module_size(ideal_module_size, opt):
@@ -198,7 +212,7 @@ class NFGR:
             load_model(phi, C_.param.init_net_path, "cpu")
         sideinfos = {**sideinfos, "data_shape": list(pre.shape), "phi_features": feats, "phi_name": opt.Module.phi.name}
         if self.precision != "fp32":
-            sideinfos["phi_precision"] = self.precision      # extra key only off the reference's fp32 path
+            sideinfos["phi_precision"] = getattr(self, "module_precision", self.precision)      # extra key only off the reference's fp32 path: what THIS net was fitted in
         dims = list(pre.shape[:-1])
         cout = pre.shape[-1]
         tgt = tgt_dev.reshape(-1, cout)

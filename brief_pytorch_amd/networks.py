@@ -115,8 +115,9 @@ class SIREN:
 
     def __init__(self, coords_channel=3, data_channel=1, features=256, layers=5, w0=30, res=False,
                  output_act=False, device=None, precision="fp32", **kwargs):
-        """precision: 'fp32' (exact f32 MFMA, the parity path) or 'bf16' (hidden GEMMs on the bf16 matrix pipe,
-        f32 master weights: the MI355X counterpart of Compress.half; include/brief_hip.h: BRIEF_PREC_BF16)."""
+        """precision: 'fp32' (exact f32 MFMA, the parity path, features <= 1024), 'bf16' (hidden GEMMs on the bf16 matrix pipe,
+        f32 master weights: the MI355X counterpart of Compress.half; include/brief_hip.h: BRIEF_PREC_BF16, features <= 512) or 'bf16x3'
+        (split precision inside the fp32 parity bands, BRIEF_PREC_BF16X3, features <= 256; training AND inference run the split chains)."""
         if res:
             # HalfResidual blocks cannot be saved by the reference's own ModelSave (SURVEY a1)
             raise NotImplementedError("SIREN(res=True) is unsupported on the fused path")

@@ -649,3 +649,29 @@ def test_device_normalisation_is_bit_identical_to_the_host_rule():
         assert side_h.keys() == side_d.keys() and all(side_h[k] == side_d[k] for k in side_h), (name, side_h, side_d)
     assert weight_is_unit(["value_65535_65535_1"]) and weight_is_unit(["none"]) and weight_is_unit([])
     assert not weight_is_unit(["value_0_100_2"]) and not weight_is_unit(["exp_100_0.5"]) and not weight_is_unit(["quantile_0_0.1_0.9_3"])
+
+
+def test_optional_precision_falls_back_to_fp32_before_any_work_when_the_net_is_too_wide(tmp_path, caplog):
+    """Compress.precision bf16x3 has kernels up to 256 features, bf16 up to 512.  A budget that solves to a wider net (in a
+    DivideTask: one large block) must not abort the job after the partition: the net is built in fp32, a warning says so, and the
+    artefact records the precision THIS net was fitted in, so that the decoder evaluates it the same way."""
+    import logging
+    from brief_pytorch_amd.synthetic import make_volume
+    vol = make_volume((12, 24, 24), seed=12)
+    path = str(tmp_path / "v.tif")
+    save_img(path, vol)
+    opt = _opt(tmp_path, 40, "none", 4.0 * SIREN.calc_param_count(3, 1, 288, 3))
+    cf = opt.CompressFramework
+    cf.Module.phi.layers = 3
+    cf.Compress.precision = "bf16x3"
+    Log = MyLogger(**opt.Log)
+    torch.manual_seed(42)
+    fw = NFGR(cf, Log=Log)
+    with caplog.at_level(logging.WARNING):
+        res = fw.compress(path)
+    assert fw.module["phi"].features == 288 and fw.module["phi"].precision == "fp32" and fw.module_precision == "fp32"
+    assert any("runs in fp32" in r.getMessage() for r in caplog.records)
+    side = config.load(os.path.join(Log.logdir, "steps40", "compressed", "sideinfos.yaml"))
+    assert side["phi_features"] == 288 and side["phi_precision"] == "fp32"
+    dec = NFGR.decompress(config.to_opt({"CompressFramework": cf}), os.path.join(Log.logdir, "steps40", "compressed", "module"), dict(side))
+    assert dec.shape == vol.shape and np.isfinite(res[40]["psnr"])

@@ -1,7 +1,7 @@
 """Randomised differential test of the C-ABI against the CPU oracle: random net shapes (layers, width, cin, cout, output_act, w0),
 batch sizes (1 ... a few thousand, ragged), loss kinds, weight maps and thresholds; forward, loss and every gradient tensor.
     python tools/fuzz_parity.py [cases] [seed] [precision]      (GPU box; prints the failing configurations, exit code 1 if any)
-precision bf16x3: widths <= 256, and the forward under test is the TRAIN kernel's yhat (its inference kernels are the fp32 ones)."""
+precision bf16x3: widths <= 256; the forward under test is the TRAIN kernel's yhat AND m.forward() (inference runs k_fused_x3<false>, the fp16-halves chains)."""
 import sys
 sys.path.insert(0, '.')
 import numpy as np, torch
@@ -18,7 +18,8 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 prec = sys.argv[3] if len(sys.argv) > 3 else 'fp32'
 worst = [0.0, 0.0, 0.0]
-widths = list(range(1, 65)) + [65, 95, 96, 97, 127, 128, 129, 160, 191, 192, 200, 223, 224, 255, 256, 257, 300, 383, 384, 385, 450, 511, 512]
+widths = list(range(1, 65)) + [65, 95, 96, 97, 127, 128, 129, 160, 191, 192, 200, 223, 224, 255, 256, 257, 288, 289, 300, 320, 383, 384, 385, 416, 450, 480, 511, 512,
+          513, 527, 544, 545, 576, 600, 640, 641, 700, 768, 769, 800, 832, 896, 897, 960, 1000, 1023, 1024]      # round 4: every tile count 9 .. 32 (k_lean)
 bad = 0
 for case in range(cases):
     L = int(rng.integers(2, 12))
@@ -27,6 +28,8 @@ for case in range(cases):
         F = int(rng.choice([96, 128, 200, 256]))
     if F > 256 and L > 6:
         L = int(rng.integers(2, 7))                      # keep the oracle quick
+    if F > 512 and L > 4:
+        L = int(rng.integers(2, 5))
     cin, cout = int(rng.choice([2, 3])), int(rng.choice([1, 1, 1, 2, 3, 4]))
     oa = bool(rng.random() < 0.15)
     w0 = float(rng.choice([10.0, 20.0, 30.0]))
@@ -49,8 +52,8 @@ for case in range(cases):
         e_f = relerr(yh, O.forward(d, p, x), 0.01 * (1.0 if oa else 100.0))
         loss, yt = m.train_step(n, torch.from_numpy(y).cuda(), coords=torch.from_numpy(x).cuda(), weights=torch.from_numpy(w).cuda() if use_w else None,
                                 loss=["datal2", "datasmoothl1"][kind], thr=thr, beta=beta, want_yhat=prec != 'fp32')
-        if prec != 'fp32':
-            e_f = relerr(yt.cpu().numpy(), O.forward(d, p, x), 0.01 * (1.0 if oa else 100.0))
+        if prec != 'fp32':      # both forwards are fuzzed: the inference kernel's (e_f above) and the TRAIN kernel's yhat
+            e_f = max(e_f, relerr(yt.cpu().numpy(), O.forward(d, p, x), 0.01 * (1.0 if oa else 100.0)))
         lo, go, _, _ = O.loss_grad(d, p, x, y, w, kind, thr, beta)
         _, go64, _, _ = O.loss_grad(d, p, x, y, w, kind, thr, beta, f64=True)
         e_l = abs(loss.item() - lo) / (abs(lo) + 1e-30)
