@@ -224,3 +224,46 @@ def test_c5_vessel_64x512x512_adaptive_mixed_blocks_at_size():
               "first-step worst gradient tensor vs oracle %.2e" % (len(names), len(sizes), sorted(set(feats)), steps, res[steps]["psnr"], res[steps]["ssim"], first, f0, worst))
     finally:
         shutil.rmtree(work, ignore_errors=True)
+
+
+def test_c5_vessel_decode_psnr_sweep_at_size():
+    """BASELINE config 5's "decode/PSNR sweep": the 64x512x512 vessel stack through NFGR.compress_divide (adaptive octree, by_dv) at three
+    compression ratios; every artefact is decoded from its stored files alone (decompress_divide) to the merged volume the run evaluated,
+    the bits spent follow the ratio, and PSNR rises with the bitrate (round-3 verdict: the sweep existed only as tools/vessel_sweep.py)."""
+    steps = 300
+    work = tempfile.mkdtemp(prefix="brief_c5s_")
+    try:
+        vol = make_vessel_volume((64, 512, 512), seed=42)
+        path = os.path.join(work, "vessel.npy")
+        np.save(path, vol)
+        rows = []
+        for ratio in (512, 128, 32):
+            opt = config.load(os.path.join(ROOT, "opt", "DivideTask", "vessel.yaml"))
+            cf = opt.CompressFramework
+            cf.Compress.divide.divide_type = "adaptive_-1_-1_0_0_20"
+            cf.Compress.divide.param_alloc = "by_dv"
+            cf.Compress.param.filesize_ratio, cf.Compress.param.given_size = ratio, 0
+            cf.Compress.max_steps, cf.Compress.checkpoints, cf.Compress.loss_log_freq = steps, "none", 10 ** 9
+            cf.Decompress.mip = False
+            cf["_seed"] = 42
+            Log = MyLogger(outputs_dir=work, project_name="r%d" % ratio, time=False)
+            torch.manual_seed(42)
+            fw = NFGR(cf, Log=Log)
+            res = fw.compress_divide(path, opt)
+            cdir = os.path.join(Log.logdir, "steps%d" % steps, "compressed")
+            names = sorted(os.listdir(os.path.join(cdir, "module")))
+            bits = 8 * sum(os.path.getsize(os.path.join(cdir, "module", nm, "module", f)) for nm in names for f in os.listdir(os.path.join(cdir, "module", nm, "module")))
+            again = fw.decompress_divide(os.path.join(cdir, "sideinfos.yaml"), os.path.join(cdir, "module"), os.path.join(cdir, "sideinfos"))
+            merged = np.load(os.path.join(Log.logdir, "steps%d" % steps, "decompressed", "vessel_decompressed.npy"))
+            assert np.array_equal(again, merged)
+            dd = merged.astype(np.float64) - vol.astype(np.float64)
+            psnr = -10 * np.log10((dd * dd).mean() / 65535.0 ** 2)
+            assert abs(psnr - res[steps]["psnr"]) < 1e-6
+            assert abs(bits / 8 - os.path.getsize(path) / ratio) / (os.path.getsize(path) / ratio) < 0.12
+            rows.append((ratio, bits / vol.size, psnr, res[steps]["ssim"], len(names)))
+            Log.close()
+        print("C5 sweep (64x512x512 vessel, %d steps): " % steps + "; ".join("ratio %d: %.4f bits/voxel, %d blocks, PSNR %.2f dB, SSIM %.4f" % (r, b, n, p, s) for r, b, p, s, n in rows))
+        assert rows[0][1] < rows[1][1] < rows[2][1]
+        assert rows[0][2] < rows[1][2] < rows[2][2]                  # more bits, better reconstruction
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
