@@ -105,8 +105,8 @@ def lib():
     L = C.CDLL(LIB_PATH)
     dp, gp, bp, vp = C.POINTER(SirenDesc), C.POINTER(GridDesc), C.POINTER(BatchDesc), C.c_void_p
     L.brief_version.restype = C.c_int
-    if L.brief_version() != 110:
-        raise BriefError("libbrief_hip.so is version %d, this binding needs 110 (brief_fit_job layout): rebuild with __graft_entry__.build()" % L.brief_version())
+    if L.brief_version() != 120:
+        raise BriefError("libbrief_hip.so is version %d, this binding needs 120 (workspace layout, widths to 1024): rebuild with __graft_entry__.build()" % L.brief_version())
     L.brief_last_error.restype = C.c_char_p
     L.brief_param_count.restype = C.c_int64
     L.brief_param_count.argtypes = [dp]

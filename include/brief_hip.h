@@ -18,7 +18,8 @@
 extern "C" {
 #endif
 
-#define BRIEF_VERSION 110 /* 0.1.1: brief_fit_job grew (lr_table, beta1_table, idx_stride); the derived weight copies carry the sine frequencies */
+#define BRIEF_VERSION 120 /* 0.1.2: features up to 1024 (k_lean), narrow-net workspaces end in a group table (brief_multi_fit trains up to 64 narrow nets per launch
+                           * pair); struct layouts as in 0.1.1 (brief_fit_job with lr_table, beta1_table, idx_stride) */
 
 typedef enum {
     BRIEF_OK = 0,

@@ -73,7 +73,7 @@ def test_capi_exports_and_sizes():
     L = _lib.lib()
     for name in _lib.EXPORTS:
         assert hasattr(L, name), name
-    assert L.brief_version() == 110
+    assert L.brief_version() == 120
     d = _lib.SirenDesc(3, 1, 5, 256, 20.0, 30.0, 0, 0)
     assert L.brief_param_count(C.byref(d)) == 198657
     assert L.brief_packed_count(C.byref(d)) == 256 * 4 + 3 * (2 * 256 * 256 + 256) + 4 * 256 + 4
