@@ -1942,13 +1942,22 @@ struct WgradArgs {
 constexpr int wgrad_nq(int NT) { return (NT + 7) / 8; }
 constexpr int wgrad_qt(int NT) { return (NT + wgrad_nq(NT) - 1) / wgrad_nq(NT); }      // exact for every compiled width (1 .. 8, 12, 16); above 16 tiles
                                                                                         // (run-time width) the last quadrant row / column may be short
-// dynamic LDS in floats: two double-buffered panel pairs, or the k-slice fold area if larger
+// How the 8 waves of a k_wgrad workgroup cover a QT x QT tile block: WMk x WNk wave tiles of TM x TN 32 x 32 tiles each, times a WK-way
+// split of every chunk's four k-groups (folded through LDS at the end).  Round 4: 5 and 6 tiles per side run 2 x 2 waves x 3 x 3 tiles
+// with k split two ways (36 tile slots for 25 / 36 tiles; they were 2 x 4 waves x 3 x 2 = 48).  7 stays 2 x 4 x (4 x 2) = 64 slots for 49
+// (4 x 4 tiles per wave would be 256 accumulator registers; seven waves of 7 x 1 tiles — 49 slots, but SIMDs 0-2 carry two waves and SIMD 3
+// one — measured 1.5 - 2 % slower), 3 stays 2 x 2 x (2 x 2) with k split two ways (one wave tile of 3 x 3 with k split four ways spilled:
+// 256 VGPRs + 192 B of scratch).
+constexpr int wgrad_wmk(int QT) { return QT >= 2 ? 2 : 1; }
+constexpr int wgrad_wnk(int QT) { return QT >= 7 ? 4 : (QT >= 2 ? 2 : 1); }
+constexpr int wgrad_wk(int QT) { return QT >= 7 ? 1 : (QT >= 2 ? 2 : 4); }
+// dynamic LDS in floats: two double-buffered panel pairs (the k-slice fold goes through them one row of wave tiles at a time)
 constexpr int wgrad_lds_floats(int NT)
 {
     const int QT = wgrad_qt(NT);
-    const int WMk = QT >= 2 ? 2 : 1, WNk = QT >= 5 ? 4 : (QT >= 2 ? 2 : 1), WK = QT >= 5 ? 1 : (QT >= 2 ? 2 : 4);
-    const int NWv = WMk * WNk, TM = (QT + WMk - 1) / WMk, TN = (QT + WNk - 1) / WNk;
-    const int fold = (WK - 1) * NWv * TM * TN * 1024 + (WK - 1) * NWv * TM * 64, panels = 4 * 32 * QT * 36;
+    const int WMk = wgrad_wmk(QT), WNk = wgrad_wnk(QT), WK = wgrad_wk(QT);
+    const int NWv = WMk * WNk, TN = (QT + WNk - 1) / WNk;
+    const int fold = (WK - 1) * NWv * TN * 1024 + (WK - 1) * NWv * 64, panels = 4 * 32 * QT * 36;
     return fold > panels ? fold : panels;
 }
 
@@ -1965,8 +1974,8 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
     // 8 waves = WMk x WNk output-tile grid x WK-way split of each chunk's four k-groups.  Wide nets spend
     // all 8 waves on output tiles; narrow ones (QT <= 4) would leave most waves without a tile, so they
     // split K instead and fold the partial accumulators through LDS at the end (fixed order).
-    constexpr int WMk = QT >= 2 ? 2 : 1, WNk = QT >= 5 ? 4 : (QT >= 2 ? 2 : 1);
-    constexpr int WK = QT >= 5 ? 1 : (QT >= 2 ? 2 : 4);
+    constexpr int WMk = wgrad_wmk(QT), WNk = wgrad_wnk(QT);
+    constexpr int WK = wgrad_wk(QT);
     constexpr int NWv = WMk * WNk;                 // waves per k-slice
     constexpr int TM = (QT + WMk - 1) / WMk, TN = (QT + WNk - 1) / WNk;
     constexpr bool MEX = QT % WMk == 0, NEX = QT % WNk == 0;   // every wave tile exists
@@ -2062,7 +2071,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
         STAMP(0)
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
-            if (WK == 1 || (kactive && (gq % WK) == wk)) {
+            if (kactive && (WK == 1 || (gq % WK) == wk)) {
                 float4 af[TM], bf[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
@@ -2114,32 +2123,30 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
 #undef WG_STAGE_A
 #undef WG_STAGE_B
     if (WK > 1) {
-        // fold the k-slices: slices 1..WK-1 park their accumulators in LDS (the panels are dead now: the
-        // loop ended on a barrier), slice 0 adds them in slice order
+        // fold the k-slices, one row of wave tiles at a time: slices 1..WK-1 park accumulator row i in LDS (the panels are dead now:
+        // the loop ended on a barrier), slice 0 adds them in slice order (row by row so that the area never exceeds the panels)
         float *red = smem;
-        float *redb = smem + (WK - 1) * NWv * TM * TN * 1024;
-        if (kactive && wk > 0) {
+        float *redb = smem + (WK - 1) * NWv * TN * 1024;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
+        for (int i = 0; i < TM; ++i) {
+            if (i > 0) lds_barrier();      // slice 0 is done with the previous row's partials
+            if (kactive && wk > 0) {
 #pragma unroll
                 for (int jn = 0; jn < TN; ++jn)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        red[((((wk - 1) * NWv + wrem) * TM + i) * TN + jn) * 1024 + r * 64 + lane] = acc[i][jn][r];
-                redb[(((wk - 1) * NWv + wrem) * TM + i) * 64 + lane] = dbacc[i];
+                        red[(((wk - 1) * NWv + wrem) * TN + jn) * 1024 + r * 64 + lane] = acc[i][jn][r];
+                redb[((wk - 1) * NWv + wrem) * 64 + lane] = dbacc[i];
             }
-        }
-        lds_barrier();
-        if (wk == 0) {
-            for (int w = 1; w < WK; ++w) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
+            lds_barrier();
+            if (wk == 0) {
+                for (int w = 1; w < WK; ++w) {
 #pragma unroll
                     for (int jn = 0; jn < TN; ++jn)
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
-                            acc[i][jn][r] += red[((((w - 1) * NWv + wrem) * TM + i) * TN + jn) * 1024 + r * 64 + lane];
-                    dbacc[i] += redb[(((w - 1) * NWv + wrem) * TM + i) * 64 + lane];
+                            acc[i][jn][r] += red[(((w - 1) * NWv + wrem) * TN + jn) * 1024 + r * 64 + lane];
+                    dbacc[i] += redb[((w - 1) * NWv + wrem) * 64 + lane];
                 }
             }
         }
