@@ -2929,7 +2929,11 @@ static int fused_grid(const brief_siren_desc &d, int64_t n, bool train)
                     (BRIEF_FUSED64 && train && nt == 8 ? (BRIEF_FUSED64 == 1 ? 2 : 3) /* k_lean<2, 2, 8> / k_lean<1, 2, 8> */ : (train ? fused_train_wpe(nt) : (nt > 8 ? 2 : 3))));
     int64_t cap = (int64_t)kCUs * (train && nt > 8 ? 1 : wpe);      // TRAIN > 8 tiles: 512-register kernel, one workgroup per CU
     if (nt >= BRIEF_LEAN_FROM)      // k_lean: what its launch bounds and its LDS image allow
-        cap = (int64_t)kCUs * (lean_wpe(1, (nt + 3) / 4) == 2 && 2 * sizeof(float) * lean_lds(1, (nt + 3) / 4, nt).total <= 160 * 1024 ? 2 : 1);
+    {
+        const int64_t by_lds = (160 * 1024) / (int64_t)(sizeof(float) * lean_lds(1, (nt + 3) / 4, nt).total);
+        const int64_t by_regs = lean_wpe(1, (nt + 3) / 4);
+        cap = (int64_t)kCUs * (by_lds < by_regs ? (by_lds > 0 ? by_lds : 1) : by_regs);
+    }
     return (int)(tiles < cap ? (tiles > 0 ? tiles : 1) : cap);
 }
 // k_fused<TRAIN> launch plan: a persistent body of `cap` workgroups over whole rounds of tiles, the rest of the batch
@@ -3176,6 +3180,9 @@ static int launch_fused(const FusedArgs &fa, int grid, hipStream_t st, hipEvent_
         break;                                                                                           \
     }
         switch (mtw) {
+#if BRIEF_LEAN_FROM < 9
+            BRIEF_WIDE(2)                    // (experiment: 5 .. 8 tiles)
+#endif
 #if BRIEF_LEAN_FROM < 17
             BRIEF_WIDE(3) BRIEF_WIDE(4)      // 257 .. 512 features
 #endif
