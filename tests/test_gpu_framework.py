@@ -69,7 +69,7 @@ def test_singletask_matches_reference_run(tmp_path, golden):
     assert np.median(d) < 40
 
 
-@pytest.mark.parametrize("L,F", [(5, 256), (4, 40), (3, 300)])
+@pytest.mark.parametrize("L,F", [(5, 256), (4, 40), (3, 300), (3, 600)])
 def test_reference_loop_body_runs_on_the_module(L, F):
     """the reference's own loop body (main.py:385-400: zero_grad, forward, loss_func, backward, torch.optim step,
     scheduler) on the duck-typed module: after requires_grad_(True) forward() is differentiable w.r.t. the parameters
