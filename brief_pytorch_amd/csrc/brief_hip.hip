@@ -3168,18 +3168,22 @@ static int launch_fused(const FusedArgs &fa, int grid, hipStream_t st, hipEvent_
         // exactly 12 or 16 tiles stays on k_fused<12 / 16, false>, whose unrolled chains decode 5 % faster: 4x384 0.89 against 0.84 of the
         // fp32 peak, 4x512 0.92 against 0.87 — tools/decode_widths.py; the layouts are the same.)
         const int mtw = (nt + 3) / 4;
+        const int rm = (nt & 3) == 1 ? 1 : ((nt & 3) == 2 ? 2 : 0);      // left-over tiles shared along K by the four waves (brief_lean.inc)
         const size_t lds = sizeof(float) * lean_lds(1, mtw, nt).total;
-        static bool attr_w[9] = {};
-#define BRIEF_WIDE(MTWV)                                                                                 \
-    case MTWV: {                                                                                         \
-        if (!attr_w[MTWV]) {                                                                             \
-            HIP_TRY(hipFuncSetAttribute((const void *)k_lean<1, MTWV, 0, TRAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+        static bool attr_w[9][3] = {};
+#define BRIEF_WIDE_RM(MTWV, RMV)                                                                         \
+    {                                                                                                    \
+        if (!attr_w[MTWV][RMV]) {                                                                        \
+            HIP_TRY(hipFuncSetAttribute((const void *)k_lean<1, MTWV, 0, TRAIN, RMV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                         (int)(sizeof(float) * lean_lds(1, MTWV, 4 * MTWV).total)));      \
-            attr_w[MTWV] = true;                                                                         \
+            attr_w[MTWV][RMV] = true;                                                                    \
         }                                                                                                \
-        launch_timed(k_lean<1, MTWV, 0, TRAIN>, grid, 256, lds, st, fa, e0, e1);                         \
-        break;                                                                                           \
+        launch_timed(k_lean<1, MTWV, 0, TRAIN, RMV>, grid, 256, lds, st, fa, e0, e1);                    \
     }
+#define BRIEF_WIDE(MTWV)                                                                                 \
+    case MTWV:                                                                                           \
+        if (rm == 1) BRIEF_WIDE_RM(MTWV, 1) else if (rm == 2) BRIEF_WIDE_RM(MTWV, 2) else BRIEF_WIDE_RM(MTWV, 0)   \
+        break;
         switch (mtw) {
 #if BRIEF_LEAN_FROM < 9
             BRIEF_WIDE(2)                    // (experiment: 5 .. 8 tiles)
@@ -3191,6 +3195,7 @@ static int launch_fused(const FusedArgs &fa, int grid, hipStream_t st, hipEvent_
         default: return fail(BRIEF_ERR_INVALID, "unsupported width");
         }
 #undef BRIEF_WIDE
+#undef BRIEF_WIDE_RM
         HIP_TRY(hipGetLastError());
         return 0;
     }

@@ -593,6 +593,68 @@ def g_half_self():
     g_half(modes=(("f32", False),), out_name="half_self")
 
 
+def g_endfit_spread(runs=None):
+    """How noisy is the REFERENCE's own end of fit on the case of half.npz?  The same fp32 fit, run k with ONE initial weight
+    moved by one ulp (the perturbation rule of tools/endfit_spread.py: numpy default_rng(0) picks layer, element and direction);
+    run 0 is the unperturbed fit (== half.npz / half_self.npz, depending on the thread count).  Stores the PSNR at the last step
+    and the minimum / median / mean of the last 200 losses per run: the distribution the HIP path's runs are compared with
+    (tests/test_gpu_parity.py::test_end_of_fit_distribution_matches_the_reference).
+        BRIEF_GOLDEN_THREADS=4 python tests/golden/make_golden.py endfit_spread      (about 10 minutes per run on 4 threads)"""
+    runs = int(os.environ.get("BRIEF_ENDFIT_RUNS", "6")) if runs is None else runs
+    vol = make_volume((24, 32, 40), seed=44)
+    steps, L_, F_ = 3000, 5, 128
+    rng = np.random.default_rng(0)
+    psnrs, mins, meds, means, picks = [], [], [], [], []
+    for k in range(runs):
+        opt = load_opt()
+        cf = opt.CompressFramework
+        cf.Compress.gpu = False
+        cf.Decompress.gpu = False
+        cf.Module.phi.layers = L_
+        cf.Module.phi.w0 = 20
+        cf.Compress.sampler.name = "randomcube"
+        cf.Compress.half = False
+        refmain.reproduc(opt.Reproduc)
+        nf = refmain.NFGR(cf)
+        nf.device = "cpu"
+        weight = refmisc.parse_weight(vol, cf.Compress.loss.weight)
+        data, side = refio.normalize_data(vol, **cf.Normalize)
+        feats, _ = nf.prepare_module(4.0 * SIREN.calc_param_count(3, 1, F_, L_, False))
+        assert feats == F_
+        phi = nf.module["phi"]
+        pick = (-1, -1, 0)
+        if k > 0:
+            l = int(rng.integers(0, L_))
+            w = phi.net[l][0].weight.data.numpy().ravel()            # a view: the assignment below edits the parameter in place
+            i = int(rng.integers(0, w.size))
+            up = bool(rng.random() < 0.5)
+            w[i] = np.nextafter(w[i], np.float32(1e9) if up else np.float32(-1e9))
+            pick = (l, i, 1 if up else -1)
+        sampler = refmain.RandomCubeSampler(data, weight, cf.Compress.coords_mode, cf.Compress.sampler.cube_count,
+                                            copy.deepcopy(cf.Compress.sampler.cube_len), steps, "cpu", True)
+        optim = refmisc.configure_optimizer(phi.parameters(), cf.Compress.optimizer_name_phi, cf.Compress.lr_phi)
+        sched = refmisc.configure_lr_scheduler(optim, cf.Compress.lr_scheduler_phi)
+        thr, _ = refio.normalize_data(np.array(cf.Compress.loss.weight_thres), **cf.Normalize, max=side["max"], min=side["min"])
+        thr = float(thr)
+        losses = []
+        for c, d, w_ in sampler:           # loop body exactly as main.py:385-400
+            optim.zero_grad()
+            yhat = phi.forward(c)
+            loss = nf.loss_func(d, yhat, w_, thr)
+            loss.backward()
+            optim.step()
+            sched.step()
+            losses.append(float(loss.item()))
+        dec = refmisc.reconstruct_flattened(list(vol.shape), 10000, nf.sample_nf, device="cpu", half=False, coords_mode=cf.Compress.coords_mode)
+        out = refio.invnormalize_data(dec.clone(), side, **cf.Normalize)
+        ps = float(refmisc.cal_psnr(vol.astype(np.float32), out.astype(np.float32), 65535))
+        tail = np.array(losses[-200:], np.float64)
+        psnrs.append(ps); mins.append(tail.min()); meds.append(np.median(tail)); means.append(tail.mean()); picks.append(pick)
+        print("reference run %d (perturbed layer, element, direction = %s): last-200 loss min %.5f median %.5f mean %.5f  PSNR %.3f dB" % (k, pick, tail.min(), np.median(tail), tail.mean(), ps), flush=True)
+        save("endfit_spread", psnr=np.array(psnrs), last200_min=np.array(mins), last200_median=np.array(meds), last200_mean=np.array(means),
+             picks=np.array(picks, np.int64), cfg=np.array([L_, F_, 20, steps]), threads=np.array([torch.get_num_threads()]))
+
+
 # ----------------------------------------------------------------------------- 11. windowed RandomCubeSampler
 def g_cube():
     """RandomCubeSampler with windows smaller than the volume (main.py:38-125): pop_size windows by unfold, cube_count

@@ -324,9 +324,10 @@ def test_trace_windowed_cube_golden(golden):
         assert np.max(np.abs(m.net[l][0].weight.data.cpu().numpy() - g["final_w%d" % l])) < 5e-5
 
 
-def _fit_half_golden(golden, precision):
+def _fit_half_golden(golden, precision, pick=None):
     """the volume, net and schedule of tests/golden/half.npz (5x128 SIREN, 24x32x40 volume, full batch, Adamax) fitted
-    by brief_siren_fit; returns (loss trace, PSNR of the decoded uint16 volume)"""
+    by brief_siren_fit; returns (loss trace, PSNR of the decoded uint16 volume).  pick = (layer, element, direction): that
+    initial weight is moved by one ulp first (tests/golden/endfit_spread.npz records the reference's runs under the same picks)"""
     from brief_pytorch_amd.fit import Fitter
     g = golden("half")
     L, F, w0, steps = (int(v) for v in g["cfg"])
@@ -334,7 +335,11 @@ def _fit_half_golden(golden, precision):
     vn, side = O.normalize(vol)
     m = SIREN(features=F, layers=L, w0=w0, precision=precision)
     for l in range(L):
-        m.net[l][0].weight.data = torch.from_numpy(g["init_w%d" % l])
+        w = g["init_w%d" % l].copy()
+        if pick is not None and int(pick[0]) == l:
+            flat = w.ravel()
+            flat[int(pick[1])] = np.nextafter(flat[int(pick[1])], np.float32(1e9) if int(pick[2]) > 0 else np.float32(-1e9))
+        m.net[l][0].weight.data = torch.from_numpy(w)
         m.net[l][0].bias.data = torch.from_numpy(g["init_b%d" % l])
     m.to(DEV)
     thr = float(O.normalize(np.array([65535], np.uint16), vmin=side["min"], vmax=side["max"])[0][0])
