@@ -379,6 +379,31 @@ def test_end_of_fit_3000_steps_golden(golden):
     assert abs(psnr - 0.5 * (p1 + p2)) < 2.5                           # one sample of the oscillation (see above)
 
 
+def test_end_of_fit_distribution_matches_the_reference(golden):
+    """Is the end of a fit on the HIP path as good as the reference's — not one sample of the last-step oscillation, but the distribution?
+    tests/golden/endfit_spread.npz holds the REFERENCE's own 3000-step fits of the half.npz case, run k with one initial weight moved by one
+    ulp (make_golden.py endfit_spread): its PSNR at the last step spreads over ~1 dB too (56.23 / 55.35 / 55.84 / ... dB), so the two runs of
+    half.npz / half_self.npz (56.26, 56.42) were the top of that distribution, not its centre.  The same perturbed fits on the HIP path must
+    give the same MEANS: PSNR within 0.5 dB, and the median / minimum of the last 200 losses (what the oscillation does not touch) within
+    4 % / 3 % (round-3 advisor: a 2.5 dB band around single samples could hide a systematic 0.5 - 1 dB loss of the fract-based phase arithmetic)."""
+    ref = golden("endfit_spread")
+    runs = len(ref["psnr"])
+    assert runs >= 4
+    ps, mins, meds = [], [], []
+    for k in range(runs):
+        pick = None if int(ref["picks"][k][0]) < 0 else ref["picks"][k]
+        _, losses, psnr = _fit_half_golden(golden, "fp32", pick=pick)
+        ps.append(psnr); mins.append(losses[-200:].min()); meds.append(np.median(losses[-200:]))
+    ps, mins, meds = np.array(ps), np.array(mins), np.array(meds)
+    print("end of fit over %d one-ulp-perturbed runs: PSNR mean %.3f (std %.2f) against the reference's %.3f (std %.2f); last-200 loss median %.4f against %.4f, "
+          "minimum %.4f against %.4f" % (runs, ps.mean(), ps.std(), ref["psnr"].mean(), ref["psnr"].std(), meds.mean(), ref["last200_median"].mean(),
+                                          mins.mean(), ref["last200_min"].mean()))
+    assert abs(ps.mean() - ref["psnr"].mean()) < 0.5
+    assert abs(meds.mean() - ref["last200_median"].mean()) < 0.04 * ref["last200_median"].mean()
+    assert abs(mins.mean() - ref["last200_min"].mean()) < 0.03 * ref["last200_min"].mean()
+    assert ps.min() > ref["psnr"].min() - 1.5 and ps.max() < ref["psnr"].max() + 1.0
+
+
 def test_decode_golden(golden):
     g = golden("decode")
     vol = g["vol"]
