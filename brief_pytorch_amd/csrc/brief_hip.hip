@@ -2916,7 +2916,7 @@ static const int g_reduce_sg_small = env_int("BRIEF_REDUCE_SG", 0, 0, 64);      
 // samples one workgroup tile covers: 32 per sample sub-tile; the split-precision TRAIN kernel walks 64-sample tiles
 static int64_t fused_wg_samples(const brief_siren_desc &d, bool train)
 {
-    if (brief_nt(d) >= BRIEF_LEAN_FROM) return 32;                                                    // k_lean<1, ...>: one 32-sample tile
+    if (d.precision == BRIEF_PREC_F32 && brief_use_lean(brief_nt(d), train)) return 32;              // k_lean<1, ...>: one 32-sample tile
     if (!train && d.precision == BRIEF_PREC_F32) return 32 * (4 / brief_wm_infer(brief_nt(d)));      // KCfg<NT, true>
     return brief_wg_samples(brief_nt(d));      // (the split-precision TRAIN kernel deals 32-sample half-tiles too, and walks them in pairs)
 }
@@ -2929,7 +2929,7 @@ static int fused_grid(const brief_siren_desc &d, int64_t n, bool train)
     const int wpe = g_wg_per_cu_set ? g_wg_per_cu : (d.precision == BRIEF_PREC_BF16X3 && (train || g_x3_decode) ? 2 /* k_fused_x3 */ :
                     (BRIEF_FUSED64 && train && nt == 8 ? (BRIEF_FUSED64 == 1 ? 2 : 3) /* k_lean<2, 2, 8> / k_lean<1, 2, 8> */ : (train ? fused_train_wpe(nt) : (nt > 8 ? 2 : 3))));
     int64_t cap = (int64_t)kCUs * (train && nt > 8 ? 1 : wpe);      // TRAIN > 8 tiles: 512-register kernel, one workgroup per CU
-    if (nt >= BRIEF_LEAN_FROM)      // k_lean: what its launch bounds and its LDS image allow
+    if (d.precision == BRIEF_PREC_F32 && brief_use_lean(nt, train))      // k_lean: what its launch bounds and its LDS image allow
     {
         const int64_t by_lds = (160 * 1024) / (int64_t)(sizeof(float) * lean_lds(1, (nt + 3) / 4, nt).total);
         const int64_t by_regs = lean_wpe(1, (nt + 3) / 4);
@@ -3163,10 +3163,10 @@ static int launch_fused(const FusedArgs &fa, int grid, hipStream_t st, hipEvent_
         return 0;
     }
 #endif
-    if (nt >= BRIEF_LEAN_FROM && (TRAIN || (nt != 12 && nt != 16))) {
-        // above 256 features: k_lean<1, MTW, 0>, a run-time number of feature tiles, MTW = ceil(nt / 4) of them per wave.  (Inference of
-        // exactly 12 or 16 tiles stays on k_fused<12 / 16, false>, whose unrolled chains decode 5 % faster: 4x384 0.89 against 0.84 of the
-        // fp32 peak, 4x512 0.92 against 0.87 — tools/decode_widths.py; the layouts are the same.)
+    if (brief_use_lean(nt, TRAIN)) {
+        // k_lean<1, MTW, 0>: a run-time number of feature tiles, MTW = ceil(nt / 4) of them per wave (brief_layout.h: brief_use_lean says
+        // which widths; inference of exactly 12 or 16 tiles stays on k_fused<12 / 16, false>, whose unrolled chains decode 5 % faster:
+        // 4x384 0.89 against 0.84 of the fp32 peak, 4x512 0.92 against 0.87 — tools/decode_widths.py; the layouts are the same)
         const int mtw = (nt + 3) / 4;
         const int rm = (nt & 3) == 1 ? 1 : ((nt & 3) == 2 ? 2 : 0);      // left-over tiles shared along K by the four waves (brief_lean.inc)
         const size_t lds = sizeof(float) * lean_lds(1, mtw, nt).total;
@@ -3185,12 +3185,8 @@ static int launch_fused(const FusedArgs &fa, int grid, hipStream_t st, hipEvent_
         if (rm == 1) BRIEF_WIDE_RM(MTWV, 1) else if (rm == 2) BRIEF_WIDE_RM(MTWV, 2) else BRIEF_WIDE_RM(MTWV, 0)   \
         break;
         switch (mtw) {
-#if BRIEF_LEAN_FROM < 9
-            BRIEF_WIDE(2)                    // (experiment: 5 .. 8 tiles)
-#endif
-#if BRIEF_LEAN_FROM < 17
+            BRIEF_WIDE(2)                    // 5 .. 7 tiles
             BRIEF_WIDE(3) BRIEF_WIDE(4)      // 257 .. 512 features
-#endif
             BRIEF_WIDE(5) BRIEF_WIDE(6) BRIEF_WIDE(7) BRIEF_WIDE(8)
         default: return fail(BRIEF_ERR_INVALID, "unsupported width");
         }
@@ -3200,14 +3196,15 @@ static int launch_fused(const FusedArgs &fa, int grid, hipStream_t st, hipEvent_
         return 0;
     }
     switch (nt) {
-        BRIEF_CASE(1) BRIEF_CASE(2) BRIEF_CASE(3) BRIEF_CASE(4)
-        BRIEF_CASE(5) BRIEF_CASE(6) BRIEF_CASE(7) BRIEF_CASE(8)
+        BRIEF_CASE(1) BRIEF_CASE(2) BRIEF_CASE(3) BRIEF_CASE(4) BRIEF_CASE(8)
+    case 7:
     case 12:
     case 16:
-        if constexpr (!TRAIN || BRIEF_LEAN_FROM > 16) {      // (the TRAIN kernels of these widths exist only in a -DBRIEF_LEAN_FROM=17 build)
-            const size_t lds12 = sizeof(float) * FusedLds<12, !TRAIN>::TOTAL, lds16 = sizeof(float) * FusedLds<16, !TRAIN>::TOTAL;
-            if (nt == 12) launch_timed(k_fused<12, TRAIN>, grid, 256, lds12, st, fa, e0, e1);
-            else launch_timed(k_fused<16, TRAIN>, grid, 256, lds16, st, fa, e0, e1);
+        if constexpr (!TRAIN) {      // inference only (their TRAIN steps run on k_lean)
+            const size_t lds7 = sizeof(float) * FusedLds<7, true>::TOTAL, lds12 = sizeof(float) * FusedLds<12, true>::TOTAL, lds16 = sizeof(float) * FusedLds<16, true>::TOTAL;
+            if (nt == 7) launch_timed(k_fused<7, false>, grid, 256, lds7, st, fa, e0, e1);
+            else if (nt == 12) launch_timed(k_fused<12, false>, grid, 256, lds12, st, fa, e0, e1);
+            else launch_timed(k_fused<16, false>, grid, 256, lds16, st, fa, e0, e1);
             break;
         }
         return fail(BRIEF_ERR_INVALID, "unsupported width");
@@ -3482,13 +3479,11 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
     case NTV:                                                                                              \
         hipLaunchKernelGGL((k_wgrad<NTV>), dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(NTV), st, wa); \
         break;
-        if (nt >= BRIEF_LEAN_FROM) {
+        if (nt > 8) {
             // run-time width: ceil(nt / 8) quadrants per side of QT = ceil(nt / quadrants) tiles (the last row / column may be short)
             const int qt = (nt + wgrad_nq(nt) - 1) / wgrad_nq(nt);
             switch (qt) {
-#if BRIEF_LEAN_FROM < 17
             case 5: hipLaunchKernelGGL((k_wgrad<0, 5>), dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(5), st, wa); break;
-#endif
             case 6: hipLaunchKernelGGL((k_wgrad<0, 6>), dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(6), st, wa); break;
             case 7: hipLaunchKernelGGL((k_wgrad<0, 7>), dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(7), st, wa); break;
             case 8: hipLaunchKernelGGL((k_wgrad<0, 8>), dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(8), st, wa); break;
@@ -3498,9 +3493,6 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
         switch (nt) {
             BRIEF_CASE(1) BRIEF_CASE(2) BRIEF_CASE(3) BRIEF_CASE(4)
             BRIEF_CASE(5) BRIEF_CASE(6) BRIEF_CASE(7) BRIEF_CASE(8)
-#if BRIEF_LEAN_FROM > 16
-            BRIEF_CASE(12) BRIEF_CASE(16)
-#endif
         }
 #undef BRIEF_CASE
         HIP_TRY(hipGetLastError());

@@ -49,21 +49,23 @@ BL_HD int64_t brief_canon_count(const brief_siren_desc &d)
 //     bp [FP]                                     s_l * bias
 //   Whp [4][FP]  (rows >= cout zero),  bhp[4]     (unscaled)
 //   (lane = 32*hi + i ; this is the operand order of v_mfma_f32_32x32x2_f32, see brief_hip.hip)
-// number of 32-feature tiles the width is padded to: exact up to 8 tiles, then 12 or 16 (only those
-// kernel instantiations exist above 256 features)
-// First tile count that runs on k_lean with an exact run-time width.  9 (round 4): every width above 256 features — 4x320 trains at
-// 0.57 of the fp32 peak instead of 0.48 as a padded 384-wide net on k_fused<12>, 4x448 at 0.66 instead of 0.61, and the exact 12- and 16-tile
-// widths gain too (0.70 / 0.78 against 0.67 / 0.77: two 256-register workgroups per CU instead of one of 512).  17 restores round 3's
-// padding of 257 .. 512 features to 384 / 512 (k_fused<12 / 16>, k_wgrad<12 / 16>).
-#ifndef BRIEF_LEAN_FROM
-#define BRIEF_LEAN_FROM 9
-#endif
+// number of 32-feature tiles of the width: exact for every fp32 net (1 .. 32 tiles)
 BL_HD int brief_nt(const brief_siren_desc &d)
 {
     const int nt = (d.features + 31) / 32;
     if (d.precision == BRIEF_PREC_BF16) return nt <= 8 ? 8 : 16;     // the bf16 kernels exist for 256 and 512 padded features
     if (d.precision == BRIEF_PREC_BF16X3) return 8;                  // split precision: one kernel set, 256 padded features (check_desc: F <= 256)
-    return nt <= 8 || nt >= BRIEF_LEAN_FROM ? nt : (nt <= 12 ? 12 : 16);      // k_lean walks a run-time number of tiles
+    return nt;
+}
+// Which exact-f32 kernel walks a net of nt tiles (round 4; measured step / decode fractions in profiles/r04_widths.md):
+//   k_fused<NT>  compile-time width, fully unrolled chains, four register arrays per wave: 1 .. 4 tiles and the 8-tile headline (TRAIN);
+//                1 .. 4, 7, 8, 12, 16 tiles (inference: its unrolled chains decode the exact 12- / 16-tile widths 5 % faster).
+//   k_lean       run-time width, rolled chains, one register array per wave, left-over tiles shared along K: everything else — 5 .. 7
+//                tiles (4x160 trains at 0.57 of the fp32 peak against 0.52, 4x192 0.67 against 0.64) and 9 .. 32 tiles.
+BL_HD bool brief_use_lean(int nt, bool train)
+{
+    if (train) return nt >= 5 && nt != 8;
+    return nt == 5 || nt == 6 || (nt >= 9 && nt != 12 && nt != 16);
 }
 BL_HD int64_t brief_pk_w0(const brief_siren_desc &) { return 0; }
 BL_HD int64_t brief_pk_hidden_stride(const brief_siren_desc &d)
@@ -127,7 +129,7 @@ BL_HD float brief_phase_scale(const brief_siren_desc &d, int l) { return (l == 0
 // --- fused-kernel geometry per NT (how the 4 waves of a workgroup split features x sample tiles)
 // Five and six feature tiles: two waves per sample tile x three tile slots each, two sample tiles per workgroup (with four waves x
 // two slots, 3 / 2 of the 8 slots were empty: 5x192 step 0.769 -> 0.701 ms, 5x160 0.598 -> 0.584); 7 tiles keep the 4 x 2 slots.
-BL_HD constexpr int brief_wm(int nt) { return nt == 5 || nt == 6 ? 2 : (nt >= 3 ? 4 : nt); }          // waves along features (TRAIN kernels, k_reduce)
+BL_HD constexpr int brief_wm(int nt) { return nt >= 3 ? 4 : nt; }          // waves along features (TRAIN kernels, k_reduce; 5 and 6 tiles were 2 x 3 slots on k_fused until round 4)
 // ... in the inference kernels (no records for k_reduce to agree with): three tiles -> one wave per sample tile owns all three (no idle
 // fourth wave: 256^3 decode of a 4x96 net 11.1 -> 8.7 ms; the TRAIN kernel spills in that form); five tiles keep 4 x 2 (25.1 ms against
 // 27.1 ms for a 4x160 net); six as above (34.2 -> 29.9 ms)

@@ -622,6 +622,27 @@ def test_multi_fit_equals_individual_fits():
         assert logs[i].shape == (18,) and torch.isfinite(logs[i]).all()
 
 
+def test_cotrained_mid_and_wide_nets_equal_their_solo_fits_under_concurrency():
+    """k_lean shares the tiles that nt % 4 leaves over along K and folds the partial tiles through LDS: a missing barrier there is a
+    RACE that only shows when other kernels perturb the timing (tools/fuzz_multifit.py found one: a co-trained 130-wide net differed from
+    its solo fit in one run of twenty).  Tile counts with one and two left-over tiles (5, 6, 9, 10, 13, 17, 18), co-trained on the
+    library's stream pool next to narrow nets, three rounds: every fit bit-identical to its solo run."""
+    from brief_pytorch_amd.fit import MultiFitter
+    shapes = [(3, 130, (16, 8, 8), "full", 0), (4, 160, (8, 16, 16), "randompoint", 1500), (3, 192, (8, 16, 16), "full", 0),
+              (3, 288, (8, 16, 16), "randompoint", 1000), (3, 320, (8, 8, 16), "full", 0), (3, 416, (8, 8, 16), "full", 0),
+              (3, 527, (8, 8, 8), "full", 0), (3, 576, (8, 8, 8), "randompoint", 700), (5, 22, (16, 16, 16), "full", 0),
+              (5, 22, (16, 16, 8), "full", 0), (3, 64, (16, 16, 16), "full", 0)]
+    for rnd in range(3):
+        solo = [_mk_fitter(L, F, d, s, n, 300 + 20 * rnd + i) for i, (L, F, d, s, n) in enumerate(shapes)]
+        group = [_mk_fitter(L, F, d, s, n, 300 + 20 * rnd + i) for i, (L, F, d, s, n) in enumerate(shapes)]
+        for f in solo:
+            f.run(16)
+        MultiFitter(group).run(16)
+        torch.cuda.synchronize()
+        for i, (a, b) in enumerate(zip(solo, group)):
+            assert torch.equal(a.m.params, b.m.params), (rnd, shapes[i])
+
+
 def test_fit_job_replays_an_index_stream_and_rejects_a_malformed_one():
     """a replayed per-step index stream (any callable t -> indices) runs inside brief_siren_fit as a device-resident
     [steps, n] tensor: same bits as step(); a stream of the wrong length or dtype is refused before the launch"""
