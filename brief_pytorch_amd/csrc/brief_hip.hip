@@ -43,6 +43,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // row of accumulator register r (0..15) inside a 32x32 tile, for lane half hi
 #define ROWMAP(r, hi) (((r) & 3) + 8 * ((r) >> 2) + 4 * (hi))
+template <int V> struct RoleC { static constexpr int value = V; };
 
 template <int NT, bool INFER = false>      // INFER: the inference kernels' wave mapping (brief_layout.h: brief_wm / brief_wm_infer)
 struct KCfg {
@@ -1943,15 +1944,24 @@ struct WgradArgs {
 constexpr int wgrad_nq(int NT) { return (NT + 7) / 8; }
 constexpr int wgrad_qt(int NT) { return (NT + wgrad_nq(NT) - 1) / wgrad_nq(NT); }      // exact for every compiled width (1 .. 8, 12, 16); above 16 tiles
                                                                                         // (run-time width) the last quadrant row / column may be short
-// How the 8 waves of a k_wgrad workgroup cover a QT x QT tile block: WMk x WNk wave tiles of TM x TN 32 x 32 tiles each, times a WK-way
-// split of every chunk's four k-groups (folded through LDS at the end).  Round 4: 5 and 6 tiles per side run 2 x 2 waves x 3 x 3 tiles
-// with k split two ways (36 tile slots for 25 / 36 tiles; they were 2 x 4 waves x 3 x 2 = 48).  7 stays 2 x 4 x (4 x 2) = 64 slots for 49
-// (4 x 4 tiles per wave would be 256 accumulator registers; seven waves of 7 x 1 tiles — 49 slots, but SIMDs 0-2 carry two waves and SIMD 3
-// one — measured 1.5 - 2 % slower), 3 stays 2 x 2 x (2 x 2) with k split two ways (one wave tile of 3 x 3 with k split four ways spilled:
-// 256 VGPRs + 192 B of scratch).
+// How the 8 waves of a k_wgrad workgroup cover a QT x QT tile block.  Rectangular form: WMk x WNk wave tiles of TM x TN 32 x 32 tiles each,
+// times a WK-way split of every chunk's four k-groups (folded through LDS at the end) — 1, 2, 4, 6 and 8 tiles per side, where it leaves no
+// slot empty (6: 2 x 2 waves x 3 x 3 tiles x two k-slices; 8: 2 x 4 waves x 4 x 2).  An odd side has no such grid (7: 64 slots for 49 tiles,
+// 5: 36 for 25, 3: 16 for 9), so there the waves take UNEQUAL pieces, sized so that the four SIMDs (which carry waves w and w + 4) end up level:
+//   LIST (3 and 5 per side)  wave w owns a run of floor(QT^2 / 8) tiles in row-major order, the last QT^2 % 8 waves one more; no k-split, no fold
+//                            (4x96 step 0.392 -> 0.432 of the fp32 peak, 4x160 0.567 -> 0.608, 4x288 0.591 -> 0.649, 4x320 0.659 -> 0.710)
+//   HET7 (7 per side)        wave w < 7 owns the first six tiles of tile row w, wave 7 the whole tile column 6: 12, 12, 12, 13 tiles per SIMD
+//                            where 16 slots were (4x224 0.647 -> 0.677, 4x448 0.736 -> 0.770, 4x640 0.693 -> 0.739, 4x896 0.733 -> 0.783)
+// Each role is a copy of the whole chunk loop (k_wgrad's chunk_loop): a role test inside the loop made the compiler carry two sets of
+// accumulators across the merge and spill (measured 20 - 25 % slower than the rectangular form it was meant to beat).  LIST at 4 and 6 per
+// side is a wash (+-1 %), at 7 it spills (two fragment reads per tile): BRIEF_WGRAD_LIST picks the sides at compile time for such A/B runs.
+#ifndef BRIEF_WGRAD_LIST
+#define BRIEF_WGRAD_LIST(QT) ((QT) == 3 || (QT) == 5)
+#endif
 constexpr int wgrad_wmk(int QT) { return QT >= 2 ? 2 : 1; }
 constexpr int wgrad_wnk(int QT) { return QT >= 7 ? 4 : (QT >= 2 ? 2 : 1); }
-constexpr int wgrad_wk(int QT) { return QT >= 7 ? 1 : (QT >= 2 ? 2 : 4); }
+constexpr bool wgrad_list(int QT) { return BRIEF_WGRAD_LIST(QT); }      // LIST mode (below): every wave owns a run of the QT^2 tiles in row-major order
+constexpr int wgrad_wk(int QT) { return QT >= 7 || wgrad_list(QT) ? 1 : (QT >= 2 ? 2 : 4); }
 // dynamic LDS in floats: two double-buffered panel pairs (the k-slice fold goes through them one row of wave tiles at a time)
 constexpr int wgrad_lds_floats(int NT)
 {
@@ -1975,10 +1985,18 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
     // 8 waves = WMk x WNk output-tile grid x WK-way split of each chunk's four k-groups.  Wide nets spend
     // all 8 waves on output tiles; narrow ones (QT <= 4) would leave most waves without a tile, so they
     // split K instead and fold the partial accumulators through LDS at the end (fixed order).
-    constexpr int WMk = wgrad_wmk(QT), WNk = wgrad_wnk(QT);
+    // LIST (5 tiles per side: 25 tiles): wave w owns tiles [3 w, 3 w + 3) of the block in row-major order, wave 7 four of them — 6, 6, 6 and 7
+    // tiles on the four SIMDs where 2 x 2 waves x (3 x 3) x two k-slices carried 9; both fragments of a tile are read per tile (LDS has the room).
+    constexpr bool LIST = wgrad_list(QT);
+    constexpr int LCNT = QT * QT / 8, LREM = QT * QT % 8;      // tiles per wave; the last LREM waves (on different SIMDs, LREM <= 4) take one more
+    constexpr bool HET7 = QT == 7 && !LIST;
+    // 7 tiles per side (HET7): no rectangular grid of equal wave tiles covers 49 tiles with fewer than 64 slots, so the waves get UNEQUAL
+    // pieces — wave w < 7 the first six tiles of tile row w, wave 7 the whole tile column 6: 12, 12, 12 and 13 tiles on the four SIMDs (a SIMD
+    // carries waves w and w + 4) instead of 16, and at most 7 accumulator tiles per wave.
+    constexpr int WMk = HET7 || LIST ? 2 : wgrad_wmk(QT), WNk = HET7 || LIST ? 4 : wgrad_wnk(QT);      // (HET7, LIST: all 8 waves in k-slice 0)
     constexpr int WK = wgrad_wk(QT);
     constexpr int NWv = WMk * WNk;                 // waves per k-slice
-    constexpr int TM = (QT + WMk - 1) / WMk, TN = (QT + WNk - 1) / WNk;
+    constexpr int TM = HET7 || LIST ? 1 : (QT + WMk - 1) / WMk, TN = LIST ? LCNT + (LREM ? 1 : 0) : (HET7 ? 7 : (QT + WNk - 1) / WNk);
     constexpr bool MEX = QT % WMk == 0, NEX = QT % WNk == 0;   // every wave tile exists
     constexpr int LDSW = 36;                       // row stride (floats): conflict-free ds_read_b128
     constexpr int NLD = (QP * 8 + 511) / 512;      // float4 loads per thread per operand per chunk
@@ -2012,6 +2030,16 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
         for (int jn = 0; jn < TN; ++jn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
+    }
+    float dbl[LIST ? TN : 1];       // LIST: row sums of every tile's A fragments (the bias gradient where the tile sits in column 0)
+    int lmt[LIST ? TN : 1], lnt[LIST ? TN : 1];
+    if (LIST) {
+        const int first = wave * LCNT + (wave > 8 - LREM ? wave - (8 - LREM) : 0);
+#pragma unroll
+        for (int k = 0; k < TN; ++k) {
+            const int t = first + k < QT * QT ? first + k : QT * QT - 1;
+            lmt[k] = t / QT; lnt[k] = t % QT; dbl[k] = 0.f;
+        }
     }
     float4 ra[NLD], rb[NLD];
     // The loop body is branch-free: the prefetch of "chunk c+2" and the staging of "chunk c+1" are
@@ -2066,10 +2094,71 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
     float st_acc[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     long long st_last = clock64();
 #endif
+    // (HET7: one copy of the whole chunk loop per role — a role test INSIDE the loop makes the compiler carry two sets of accumulators
+    //  through the merge points and spill; every wave meets the same barriers in either copy)
+    auto chunk_loop = [&](auto role_c) __attribute__((always_inline)) {
+    constexpr int ROLE = decltype(role_c)::value;
     for (int64_t c = c0; c < c1; ++c) {
         const int cur = (int)(c - c0) & 1;
         const float *As = smem + cur * 2 * PANEL, *Bs = As + PANEL;
         STAMP(0)
+        if constexpr (LIST) {
+            constexpr int CNT = LCNT + ROLE;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+#pragma unroll
+                for (int k = 0; k < CNT; ++k) {
+                    const float4 a_ = *reinterpret_cast<const float4 *>(As + (32 * lmt[k] + ln) * LDSW + 8 * gq + 4 * hi);
+                    const float4 b_ = *reinterpret_cast<const float4 *>(Bs + (32 * lnt[k] + ln) * LDSW + 8 * gq + 4 * hi);
+                    dbl[k] += (a_.x + a_.y) + (a_.z + a_.w);
+                    acc[0][k] = MFMA(a_.x, b_.x, acc[0][k]); acc[0][k] = MFMA(a_.y, b_.y, acc[0][k]);
+                    acc[0][k] = MFMA(a_.z, b_.z, acc[0][k]); acc[0][k] = MFMA(a_.w, b_.w, acc[0][k]);
+                }
+                if (gq >= 2) {
+#pragma unroll
+                    for (int i = 0; i < NLD; ++i)
+                        if ((i & 1) == (gq & 1)) { WG_STAGE_A(cur ^ 1, i) WG_STAGE_B(cur ^ 1, i) }
+                }
+            }
+        } else if constexpr (HET7) {
+            // two wave-uniform roles, each a straight-line stream of its own over the chunk's four k-groups (the role test sits OUTSIDE
+            // the k-group loop so that each stream keeps its own software pipeline of fragment reads under the MFMAs)
+#define WG_FRAG(P, row) (*reinterpret_cast<const float4 *>((P) + (32 * (row) + ln) * LDSW + 8 * gq + 4 * hi))
+#define WG_MFMA4(k, A_, B_) { acc[0][k] = MFMA((A_).x, (B_).x, acc[0][k]); acc[0][k] = MFMA((A_).y, (B_).y, acc[0][k]); \
+                              acc[0][k] = MFMA((A_).z, (B_).z, acc[0][k]); acc[0][k] = MFMA((A_).w, (B_).w, acc[0][k]); }
+#define WG_STAGE_NEXT                                                                   \
+            if (gq >= 2) {                                                              \
+                _Pragma("unroll") for (int i = 0; i < NLD; ++i)                         \
+                    if ((i & 1) == (gq & 1)) { WG_STAGE_A(cur ^ 1, i) WG_STAGE_B(cur ^ 1, i) } \
+            }
+            if constexpr (ROLE == 0) {
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const float4 a_ = WG_FRAG(As, wave);
+                    dbacc[0] += (a_.x + a_.y) + (a_.z + a_.w);
+#pragma unroll
+                    for (int jn = 0; jn < 6; ++jn) {
+                        const float4 b_ = WG_FRAG(Bs, jn);
+                        WG_MFMA4(jn, a_, b_)
+                    }
+                    WG_STAGE_NEXT
+                }
+            } else {
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const float4 b6 = WG_FRAG(Bs, 6);
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) {
+                        const float4 a_ = WG_FRAG(As, i);
+                        WG_MFMA4(i, a_, b6)
+                    }
+                    WG_STAGE_NEXT
+                }
+            }
+#undef WG_FRAG
+#undef WG_MFMA4
+#undef WG_STAGE_NEXT
+        } else
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
             if (kactive && (WK == 1 || (gq % WK) == wk)) {
@@ -2117,6 +2206,9 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
         lds_barrier();
         STAMP(3)
     }
+    };
+    if (LIST ? (LREM > 0 && wave >= 8 - LREM) : (HET7 && wave == 7)) chunk_loop(RoleC<1>{});
+    else chunk_loop(RoleC<0>{});
 #ifdef BRIEF_STAMPS
     if (lane == 0 && a.stamps) for (int i = 0; i < 4; ++i) a.stamps[((int64_t)blockIdx.x * 8 + wave) * 8 + i] = st_acc[i];
 #endif
@@ -2154,6 +2246,41 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const WgradArgs a)
     }
     if (wk != 0) return;
     float *slab = a.slabs + ((int64_t)(l - 1) * a.nsplit + split) * ((int64_t)FP * FP + FP);
+    if (LIST) {
+        const int cnt = LCNT + (LREM > 0 && wave >= 8 - LREM ? 1 : 0);
+#pragma unroll
+        for (int k = 0; k < TN; ++k) {
+            if (k >= cnt) break;
+            const int mt = lmt[k], nt = lnt[k];
+            if ((!RTW || qm * QT + mt < nt_w) && (!RTW || qn * QT + nt < nt_w)) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    slab[(int64_t)(qm * QP + 32 * mt + ROWMAP(r, hi)) * FP + qn * QP + 32 * nt + ln] = acc[0][k][r];
+            }
+            if (qn == 0 && nt == 0) {
+                const float tot = dbl[k] + __shfl_xor(dbl[k], 32);
+                if (hi == 0 && (!RTW || qm * QT + mt < nt_w)) slab[(int64_t)FP * FP + qm * QP + 32 * mt + ln] = tot;
+            }
+        }
+        return;
+    }
+    if (HET7) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const int mt = wave < 7 ? wave : k, nt = wave < 7 ? k : 6;
+            if (wave < 7 && k == 6) continue;
+            if ((!RTW || qm * QT + mt < nt_w) && (!RTW || qn * QT + nt < nt_w)) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    slab[(int64_t)(qm * QP + 32 * mt + ROWMAP(r, hi)) * FP + qn * QP + 32 * nt + ln] = acc[0][k][r];
+            }
+        }
+        if (qn == 0 && wave < 7) {      // bias gradients: tile row w from wave w
+            const float tot = dbacc[0] + __shfl_xor(dbacc[0], 32);
+            if (hi == 0 && (!RTW || qm * QT + wave < nt_w)) slab[(int64_t)FP * FP + qm * QP + 32 * wave + ln] = tot;
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int mt = wmk * TM + i;
