@@ -440,6 +440,9 @@ struct FusedLds {
 };
 
 #ifndef BRIEF_FUSED64
+#ifndef BRIEF_LEAN_RM3
+#define BRIEF_LEAN_RM3 1     // nt % 4 == 3: the three left-over tiles shared along K (lean_chain_rt3); 0: wave 3 computes a duplicate (A/B)
+#endif
 #define BRIEF_FUSED64 0      // 1: the 8-tile TRAIN step walks 64-sample tiles (k_lean<2, 2, 8>) instead of k_fused<8>'s 32-sample tiles
 #endif
 #ifndef BRIEF_KERNARG_RELOAD
@@ -3295,9 +3298,9 @@ static int launch_fused(const FusedArgs &fa, int grid, hipStream_t st, hipEvent_
         // which widths; inference of exactly 12 or 16 tiles stays on k_fused<12 / 16, false>, whose unrolled chains decode 5 % faster:
         // 4x384 0.89 against 0.84 of the fp32 peak, 4x512 0.92 against 0.87 — tools/decode_widths.py; the layouts are the same)
         const int mtw = (nt + 3) / 4;
-        const int rm = (nt & 3) == 1 ? 1 : ((nt & 3) == 2 ? 2 : 0);      // left-over tiles shared along K by the four waves (brief_lean.inc)
+        const int rm = BRIEF_LEAN_RM3 ? (nt & 3) : ((nt & 3) == 3 ? 0 : (nt & 3));      // left-over tiles shared along K by the four waves (brief_lean.inc)
         const size_t lds = sizeof(float) * lean_lds(1, mtw, nt).total;
-        static bool attr_w[9][3] = {};
+        static bool attr_w[9][4] = {};
 #define BRIEF_WIDE_RM(MTWV, RMV)                                                                         \
     {                                                                                                    \
         if (!attr_w[MTWV][RMV]) {                                                                        \
@@ -3309,7 +3312,7 @@ static int launch_fused(const FusedArgs &fa, int grid, hipStream_t st, hipEvent_
     }
 #define BRIEF_WIDE(MTWV)                                                                                 \
     case MTWV:                                                                                           \
-        if (rm == 1) BRIEF_WIDE_RM(MTWV, 1) else if (rm == 2) BRIEF_WIDE_RM(MTWV, 2) else BRIEF_WIDE_RM(MTWV, 0)   \
+        if (rm == 1) BRIEF_WIDE_RM(MTWV, 1) else if (rm == 2) BRIEF_WIDE_RM(MTWV, 2) else if (rm == 3) BRIEF_WIDE_RM(MTWV, 3) else BRIEF_WIDE_RM(MTWV, 0)   \
         break;
         switch (mtw) {
             BRIEF_WIDE(2)                    // 5 .. 7 tiles
