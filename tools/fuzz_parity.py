@@ -49,7 +49,11 @@ for case in range(cases):
     tag = "case %d: L=%d F=%d cin=%d cout=%d oa=%d w0=%g n=%d loss=%d thr=%g beta=%g weights=%d" % (case, L, F, cin, cout, oa, w0, n, kind, thr, beta, use_w)
     try:
         yh = m.forward(torch.from_numpy(x).cuda()).cpu().numpy()
-        e_f = relerr(yh, O.forward(d, p, x), 0.01 * (1.0 if oa else 100.0))
+        yo = O.forward(d, p, x)
+        e_f = relerr(yh, yo, 0.01 * (1.0 if oa else 100.0))
+        # conditioning of the forward (a deep narrow net under a sine head multiplies every rounding error by w0 per layer): the band is 2e-5
+        # or three times the oracle's own f32 <-> f64 distance, whichever is larger
+        f_band = max(2e-5, 3.0 * relerr(yo, O.forward(d, p, x, f64=True), 0.01 * (1.0 if oa else 100.0)))
         loss, yt = m.train_step(n, torch.from_numpy(y).cuda(), coords=torch.from_numpy(x).cuda(), weights=torch.from_numpy(w).cuda() if use_w else None,
                                 loss=["datal2", "datasmoothl1"][kind], thr=thr, beta=beta, want_yhat=prec != 'fp32')
         if prec != 'fp32':      # both forwards are fuzzed: the inference kernel's (e_f above) and the TRAIN kernel's yhat
@@ -71,17 +75,17 @@ for case in range(cases):
                 # a tensor whose gradient is (numerically) zero everywhere has no max-abs of its own to be relative to
                 scale = max(float(np.max(np.abs(b))), 1e-6 * gmax, 1e-30)
                 e_g = max(e_g, float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))) / scale))
-        # (a loss that is a small difference of O(1) numbers - one sample, sine head - is only as exact as yhat is)
-        ok = e_f < 2e-5 and abs(loss.item() - lo) <= 1e-5 * max(abs(lo), 1e-2 * float(np.mean(y.astype(np.float64) ** 2))) and e_g < g_band and np.isfinite(loss.item())
+        # (a loss that is a small difference of O(1) numbers - one sample, sine head - is only as exact as yhat is: its band widens with the forward's)
+        ok = e_f < f_band and abs(loss.item() - lo) <= 1e-5 * (f_band / 2e-5) * max(abs(lo), 1e-2 * float(np.mean(y.astype(np.float64) ** 2))) and e_g < g_band and np.isfinite(loss.item())
     except Exception as ex:
         ok, e_f, e_l, e_g = False, -1, -1, -1
         tag += "  EXCEPTION %r" % (ex,)
     if e_f >= 0 and e_g < 1.0:
-        worst = [max(worst[0], e_f), max(worst[1], e_l), max(worst[2], e_g / (g_band / 1e-4))]
+        worst = [max(worst[0], e_f / (f_band / 2e-5)), max(worst[1], e_l), max(worst[2], e_g / (g_band / 1e-4))]
     if not ok:
         bad += 1
         print("FAIL %s  forward %.2e loss %.2e grads %.2e" % (tag, e_f, e_l, e_g), flush=True)
     elif case % 25 == 0:
         print("ok   %s  forward %.1e loss %.1e grads %.1e" % (tag, e_f, e_l, e_g), flush=True)
-print("%d cases, %d failures; worst forward %.2e (band 2e-5), loss %.2e, gradients %.2e of a 1e-4 band (conditioning-scaled)" % (cases, bad, worst[0], worst[1], worst[2]))
+print("%d cases, %d failures; worst forward %.2e of a 2e-5 band (conditioning-scaled), loss %.2e, gradients %.2e of a 1e-4 band (conditioning-scaled)" % (cases, bad, worst[0], worst[1], worst[2]))
 sys.exit(1 if bad else 0)
