@@ -60,8 +60,8 @@ BL_HD int brief_nt(const brief_siren_desc &d)
 // Which exact-f32 kernel walks a net of nt tiles (round 4; measured step / decode fractions in profiles/r04_widths.md):
 //   k_fused<NT>  compile-time width, fully unrolled chains, four register arrays per wave: 1 .. 4 tiles and the 8-tile headline (TRAIN);
 //                1 .. 4, 7, 8, 12, 16 tiles (inference: its unrolled chains decode the exact 12- / 16-tile widths 5 % faster).
-//   k_lean       run-time width, rolled chains, one register array per wave, left-over tiles shared along K: everything else — 5 .. 7
-//                tiles (4x160 trains at 0.57 of the fp32 peak against 0.52, 4x192 0.67 against 0.64) and 9 .. 32 tiles.
+//   k_lean       run-time width, rolled chains, one register array per wave, left-over tiles (nt % 4 = 1, 2, 3) shared along K: everything
+//                else — 5 .. 7 tiles (4x160 trains at 0.61 of the fp32 peak against 0.52, 4x192 0.67 against 0.64) and 9 .. 32 tiles.
 BL_HD bool brief_use_lean(int nt, bool train)
 {
     if (train) return nt >= 5 && nt != 8;
