@@ -10,8 +10,9 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BRIEF_LIB", os.path.join(_HERE, "libbrief_hip.so"))   # BRIEF_LIB: A/B diagnostics only
 SRC = os.path.join(_HERE, "csrc", "brief_hip.hip")
-_DEPS = [SRC, os.path.join(_HERE, "csrc", "brief_layout.h"), os.path.join(_HERE, "csrc", "brief_math.h"), os.path.join(_HERE, "csrc", "brief_bf16.inc"),
-         os.path.join(os.path.dirname(_HERE), "include", "brief_hip.h")]
+_CSRC = os.path.join(_HERE, "csrc")
+# every file of the translation unit (brief_hip.hip includes the *.inc / *.h beside it) and the public header
+_DEPS = sorted(os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".inc", ".h"))) + [os.path.join(os.path.dirname(_HERE), "include", "brief_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 

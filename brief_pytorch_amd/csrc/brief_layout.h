@@ -48,7 +48,7 @@ BL_HD int64_t brief_canon_count(const brief_siren_desc &d)
 //                                                 (delta_{l-1} = (w0_{l-1} W_l^T delta_l) . cos(phase_{l-1}))
 //     bp [FP]                                     s_l * bias
 //   Whp [4][FP]  (rows >= cout zero),  bhp[4]     (unscaled)
-//   (lane = 32*hi + i ; this is the operand order of v_mfma_f32_32x32x2_f32, see brief_hip.hip)
+//   (lane = 32*hi + i ; this is the operand order of v_mfma_f32_32x32x2_f32, see brief_device.inc)
 // number of 32-feature tiles of the width: exact for every fp32 net (1 .. 32 tiles)
 BL_HD int brief_nt(const brief_siren_desc &d)
 {
