@@ -146,7 +146,7 @@ static const int g_reduce_sg_small = env_int("BRIEF_REDUCE_SG", 0, 0, 64);      
 // samples one workgroup tile covers: 32 per sample sub-tile; the split-precision TRAIN kernel walks 64-sample tiles
 static int64_t fused_wg_samples(const brief_siren_desc &d, bool train)
 {
-    if (d.precision == BRIEF_PREC_F32 && brief_use_lean(brief_nt(d), train)) return 32;              // k_lean<1, ...>: one 32-sample tile
+    if (d.precision == BRIEF_PREC_F32 && brief_use_lean(d, train)) return 32;              // k_lean<1, ...>: one 32-sample tile
     if (!train && d.precision == BRIEF_PREC_F32) return 32 * (4 / brief_wm_infer(brief_nt(d)));      // KCfg<NT, true>
     return brief_wg_samples(brief_nt(d));      // (the split-precision TRAIN kernel deals 32-sample half-tiles too, and walks them in pairs)
 }
@@ -159,7 +159,7 @@ static int fused_grid(const brief_siren_desc &d, int64_t n, bool train)
     const int wpe = g_wg_per_cu_set ? g_wg_per_cu : (d.precision == BRIEF_PREC_BF16X3 && (train || g_x3_decode) ? 2 /* k_fused_x3 */ :
                     (BRIEF_FUSED64 && train && nt == 8 ? (BRIEF_FUSED64 == 1 ? 2 : 3) /* k_lean<2, 2, 8> / k_lean<1, 2, 8> */ : (train ? fused_train_wpe(nt) : (nt > 8 ? 2 : 3))));
     int64_t cap = (int64_t)kCUs * (train && nt > 8 ? 1 : wpe);      // TRAIN > 8 tiles: 512-register kernel, one workgroup per CU
-    if (d.precision == BRIEF_PREC_F32 && brief_use_lean(nt, train))      // k_lean: what its launch bounds and its LDS image allow
+    if (d.precision == BRIEF_PREC_F32 && brief_use_lean(d, train))      // k_lean: what its launch bounds and its LDS image allow
     {
         const int64_t by_lds = (160 * 1024) / (int64_t)(sizeof(float) * lean_lds(1, (nt + 3) / 4, nt).total);
         const int64_t by_regs = lean_wpe(1, (nt + 3) / 4);
@@ -393,7 +393,7 @@ static int launch_fused(const FusedArgs &fa, int grid, hipStream_t st, hipEvent_
         return 0;
     }
 #endif
-    if (brief_use_lean(nt, TRAIN)) {
+    if (brief_use_lean(fa.d, TRAIN)) {
         // k_lean<1, MTW, 0>: a run-time number of feature tiles, MTW = ceil(nt / 4) of them per wave (brief_layout.h: brief_use_lean says
         // which widths; inference of exactly 12 or 16 tiles stays on k_fused<12 / 16, false>, whose unrolled chains decode 5 % faster:
         // 4x384 0.89 against 0.84 of the fp32 peak, 4x512 0.92 against 0.87 — tools/decode_widths.py; the layouts are the same)
