@@ -53,7 +53,8 @@ def test_forward_golden(golden, tag):
 @pytest.mark.parametrize("L,F,cin,cout,n", [(2, 16, 3, 1, 100), (3, 33, 3, 1, 31), (4, 96, 2, 3, 1000), (5, 130, 3, 1, 257),
                                              (6, 200, 3, 1, 65), (3, 224, 3, 3, 1), (5, 256, 3, 1, 4097), (9, 64, 3, 1, 513),
                                              (4, 300, 3, 1, 200), (3, 512, 3, 1, 100), (9, 512, 3, 1, 257),
-                                             (4, 340, 3, 1, 300), (3, 480, 3, 1, 150)])      # 11 / 15 tiles: three left-over tiles shared along K
+                                             (4, 340, 3, 1, 300), (3, 480, 3, 1, 150),       # 11 / 15 tiles: three left-over tiles shared along K
+                                             (4, 290, 3, 1, 260), (3, 430, 3, 1, 140), (4, 330, 2, 1, 100), (5, 130, 3, 1, 700)])      # partial last k-tile (1, 2, 2, 1 real steps) under every sharing mode
 def test_forward_shapes_vs_oracle(L, F, cin, cout, n):
     m, d, p = make_net(L, F, 20.0, cin, cout, seed=L * 100 + F)
     x = np.random.default_rng(F).uniform(-1, 1, size=(n, cin)).astype(np.float32)
@@ -118,7 +119,9 @@ def test_loss_grads_golden(golden, tag):
                                                 (5, 256, 3, 1, 9000, False), (9, 64, 3, 1, 513, False), (4, 48, 3, 1, 777, True),
                                                 (4, 300, 3, 1, 700, False), (3, 512, 2, 3, 300, False), (5, 512, 3, 1, 1500, False),
                                                 # 11 / 15 tiles (three left-over tiles shared along K, 2 x 6 / 2 x 8 k_wgrad quadrants), 14 tiles (7-tile quadrants)
-                                                (4, 340, 3, 1, 1200, False), (3, 480, 3, 2, 900, False), (4, 440, 2, 1, 700, False)])
+                                                (4, 340, 3, 1, 1200, False), (3, 480, 3, 2, 900, False), (4, 440, 2, 1, 700, False),
+                                                # a partial last k-tile (37 / 54 / 42 / 87 steps) under two, two, three and two shared left-over tiles
+                                                (4, 290, 3, 1, 600, False), (3, 430, 3, 1, 500, False), (4, 330, 2, 1, 400, False), (3, 690, 3, 1, 300, False)])
 def test_train_step_shapes_vs_oracle(L, F, cin, cout, n, oa):
     m, d, p = make_net(L, F, 20.0, cin, cout, oa, seed=L * 10 + F)
     rng = np.random.default_rng(F + n)
