@@ -17,6 +17,7 @@ def relerr(a, b, floor=0.0):
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 prec = sys.argv[3] if len(sys.argv) > 3 else 'fp32'
+detail = int(sys.argv[4]) if len(sys.argv) > 4 else -1      # print every tensor's distances for this case
 worst = [0.0, 0.0, 0.0]
 widths = list(range(1, 65)) + [65, 95, 96, 97, 127, 128, 129, 160, 191, 192, 200, 223, 224, 255, 256, 257, 288, 289, 300, 320, 383, 384, 385, 416, 450, 480, 511, 512,
           513, 527, 544, 545, 576, 600, 640, 641, 700, 768, 769, 800, 832, 896, 897, 960, 1000, 1023, 1024]      # round 4: every tile count 9 .. 32 (k_lean)
@@ -58,7 +59,7 @@ for case in range(cases):
                                 loss=["datal2", "datasmoothl1"][kind], thr=thr, beta=beta, want_yhat=prec != 'fp32')
         if prec != 'fp32':      # both forwards are fuzzed: the inference kernel's (e_f above) and the TRAIN kernel's yhat
             e_f = max(e_f, relerr(yt.cpu().numpy(), O.forward(d, p, x), 0.01 * (1.0 if oa else 100.0)))
-        lo, go, _, _ = O.loss_grad(d, p, x, y, w, kind, thr, beta)
+        lo, go, yho, _ = O.loss_grad(d, p, x, y, w, kind, thr, beta)
         _, go64, _, _ = O.loss_grad(d, p, x, y, w, kind, thr, beta, f64=True)
         e_l = abs(loss.item() - lo) / (abs(lo) + 1e-30)
         gw, gb = O.unpack_params(d, go)
@@ -67,13 +68,28 @@ for case in range(cases):
         # rounding error by w0 per layer); the band is 1e-4 or three times that, whichever is larger
         cond = max(max(relerr(gw[l], gw64[l]), relerr(gb[l], gb64[l])) for l in range(L))
         g_band = max(1e-4, 3.0 * cond)
+        if kind == 1:
+            # smooth-L1 has a kink at |yhat - y| = beta (slope df / beta inside, +-1 outside meet there, but a sample that sits within the forward's
+            # rounding of it and lands on different sides in the two implementations changes its own term by up to that rounding / beta): the band
+            # widens by one sample's share for every sample that close
+            near = np.abs(np.abs(np.asarray(yho, np.float64) - y) - beta) < 1e-5 * np.maximum(1.0, np.abs(y))
+            g_band += float(np.count_nonzero(near)) * 2.0 / max(1, n * cout)
         mw, mb = O.unpack_params(d, m.grads.cpu().numpy())
         gmax = max(float(np.max(np.abs(t))) for t in list(gw) + list(gb))
+        if case == detail:
+            for l in range(L):
+                print("  layer %d: W hip-o32 %.2e  o32-o64 %.2e  max|g| %.2e   b hip-o32 %.2e  o32-o64 %.2e  max|g| %.2e" % (
+                    l, relerr(mw[l], gw[l]), relerr(gw[l], gw64[l]), float(np.max(np.abs(gw[l]))), relerr(mb[l], gb[l]), relerr(gb[l], gb64[l]), float(np.max(np.abs(gb[l])))))
+                if F <= 2:
+                    print("    W hip", np.asarray(mw[l]).ravel()[:4], "o32", np.asarray(gw[l]).ravel()[:4], "o64", np.asarray(gw64[l]).ravel()[:4])
         e_g = 0.0
         for l in range(L):
             for a, b in ((mw[l], gw[l]), (mb[l], gb[l])):
                 # a tensor whose gradient is (numerically) zero everywhere has no max-abs of its own to be relative to
-                scale = max(float(np.max(np.abs(b))), 1e-6 * gmax, 1e-30)
+                # ... and a tensor whose gradient nearly cancels over the batch (case 523 of seed 101: a bias gradient of 7e-4 summed from 128 terms of
+                # ~0.5 beside gradients of 1.9) carries the ~1e-6 absolute error of v_sin / v_cos in every term: an absolute 3e-6 there is the f32
+                # level of the NET's gradients, not 4e-3 of anything.  Hence a floor of 5e-2 of the largest gradient under the 1e-4 band (5e-6 absolute).
+                scale = max(float(np.max(np.abs(b))), 5e-2 * gmax, 1e-30)
                 e_g = max(e_g, float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))) / scale))
         # (a loss that is a small difference of O(1) numbers - one sample, sine head - is only as exact as yhat is: its band widens with the forward's)
         ok = e_f < f_band and abs(loss.item() - lo) <= 1e-5 * (f_band / 2e-5) * max(abs(lo), 1e-2 * float(np.mean(y.astype(np.float64) ** 2))) and e_g < g_band and np.isfinite(loss.item())
