@@ -48,10 +48,16 @@ PEAKS = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "bf16x3": 
 DTYPES = {"fp32": "f32", "bf16": "bf16", "bf16x3": "bf16x3"}
 
 
+def train_on_lean(F):
+    """csrc/brief_layout.h: brief_use_lean(train): every tile count from 5 on except the 8-tile headline"""
+    nt = (F + 31) // 32
+    return nt >= 5 and nt != 8
+
+
 def fused_kernel_name(precision, F):
-    if precision == "fp32" and F > 512:
+    if precision == "fp32" and train_on_lean(F):
         nt = (F + 31) // 32
-        return "k_lean<1,%d,0,true> (%d feature tiles, run-time width)" % ((nt + 3) // 4, nt)
+        return "k_lean<1,%d,0,true,%d> (%d feature tiles, run-time width)" % ((nt + 3) // 4, nt % 4, nt)
     if precision == "fp32":
         return "k_fused<%d,true>" % ((F + 31) // 32)
     if precision == "bf16x3":
@@ -334,7 +340,7 @@ def timed_config(name, L, F, dims, sampler, n, precision, steps, tgt=None, seed=
     return {**dec, "workload": name, "layers": L, "features": F, "volume": list(dims), "samples_per_step": nb, "dtype": DTYPES[precision],
             "steps": steps, "ms_per_step": el * 1e3 / steps, "voxels_per_s": nb * steps / el,
             "step_tflops": train_f * nb / (el / steps) / 1e12, "step_frac": train_f * nb / (el / steps) / 1e12 / peak,
-            "kernel": "k_small" if small else {"fp32": "k_lean" if F > 512 else "k_fused", "bf16x3": "k_fused_x3<true>", "bf16": "k16 (body + tail launches)"}[precision],
+            "kernel": "k_small" if small else {"fp32": "k_lean" if train_on_lean(F) else "k_fused", "bf16x3": "k_fused_x3<true>", "bf16": "k16 (body + tail launches)"}[precision],
             "kernel_ms": kms, "kernel_tflops": kflop / (kms * 1e-3) / 1e12, "kernel_frac": kflop / (kms * 1e-3) / 1e12 / peak, "peak_tflops": peak}
 
 
@@ -596,6 +602,12 @@ def main():
                                                              "the whole grid (262144 samples per step), Adamax", 3, 64, (64, 64, 64), "full", 0, "fp32", 400)
             cfgs["default_yaml_64cube_4x22"] = timed_config("SingleTask default.yaml on a 64^3 volume: the budget solves to SIREN 4x22 (layers=5, features=22), "
                                                             "full-volume batch", 5, 22, (64, 64, 64), "full", 0, "fp32", 400)
+            # the shipped default.yaml over volume sizes: its byte budget (ratio 80) solves to 22 / 65 / 186 / 527 features on 64^3 / 128^3 / 256^3 / 512^3
+            # uint16 volumes (SIREN.calc_features), i.e. k_small, k_fused<3>, k_lean with two slots per wave and k_lean with five
+            cfgs["default_yaml_128cube_4x65"] = timed_config("SingleTask default.yaml on a 128^3 uint16 volume: the budget solves to SIREN 4x65 (3 feature tiles), "
+                                                             "randompoint sample_size=100000; k_fused<3> + k_wgrad<3>", 5, 65, (128, 128, 128), "randompoint", SAMPLE, "fp32", 200)
+            cfgs["default_yaml_256cube_4x186"] = timed_config("SingleTask default.yaml on a 256^3 uint16 volume: the budget solves to SIREN 4x186 (6 feature tiles), "
+                                                              "randompoint sample_size=100000; k_lean + k_wgrad<6>", 5, 186, (256, 256, 256), "randompoint", SAMPLE, "fp32", 100)
             cfgs["default_yaml_512cube_4x527"] = timed_config("SingleTask default.yaml (ratio 80) on the 512^3 uint16 volume: the budget solves to SIREN 4x527 "
                                                               "(layers=5, features=527 = 17 feature tiles), randompoint sample_size=100000; k_lean + k_wgrad<0,6>",
                                                               5, 527, BLOCK, "randompoint", SAMPLE, "fp32", 40, tgt=tgt)
