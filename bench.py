@@ -49,9 +49,9 @@ DTYPES = {"fp32": "f32", "bf16": "bf16", "bf16x3": "bf16x3"}
 
 
 def train_on_lean(F):
-    """csrc/brief_layout.h: brief_use_lean(train): every tile count from 5 on except the 8-tile headline"""
+    """csrc/brief_layout.h: brief_use_lean(train): 3 tiles and every tile count from 5 on except the 8-tile headline"""
     nt = (F + 31) // 32
-    return nt >= 5 and nt != 8
+    return (nt >= 5 and nt != 8) or nt == 3
 
 
 def fused_kernel_name(precision, F):
@@ -603,9 +603,9 @@ def main():
             cfgs["default_yaml_64cube_4x22"] = timed_config("SingleTask default.yaml on a 64^3 volume: the budget solves to SIREN 4x22 (layers=5, features=22), "
                                                             "full-volume batch", 5, 22, (64, 64, 64), "full", 0, "fp32", 400)
             # the shipped default.yaml over volume sizes: its byte budget (ratio 80) solves to 22 / 65 / 186 / 527 features on 64^3 / 128^3 / 256^3 / 512^3
-            # uint16 volumes (SIREN.calc_features), i.e. k_small, k_fused<3>, k_lean with two slots per wave and k_lean with five
+            # uint16 volumes (SIREN.calc_features), i.e. k_small, k_lean with one, two and five slots per wave
             cfgs["default_yaml_128cube_4x65"] = timed_config("SingleTask default.yaml on a 128^3 uint16 volume: the budget solves to SIREN 4x65 (3 feature tiles), "
-                                                             "randompoint sample_size=100000; k_fused<3> + k_wgrad<3>", 5, 65, (128, 128, 128), "randompoint", SAMPLE, "fp32", 200)
+                                                             "randompoint sample_size=100000; k_lean<1,1,0,true,3> + k_wgrad<3>", 5, 65, (128, 128, 128), "randompoint", SAMPLE, "fp32", 200)
             cfgs["default_yaml_256cube_4x186"] = timed_config("SingleTask default.yaml on a 256^3 uint16 volume: the budget solves to SIREN 4x186 (6 feature tiles), "
                                                               "randompoint sample_size=100000; k_lean + k_wgrad<6>", 5, 186, (256, 256, 256), "randompoint", SAMPLE, "fp32", 100)
             cfgs["default_yaml_512cube_4x527"] = timed_config("SingleTask default.yaml (ratio 80) on the 512^3 uint16 volume: the budget solves to SIREN 4x527 "

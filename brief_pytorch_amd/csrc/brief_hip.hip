@@ -415,6 +415,7 @@ static int launch_fused(const FusedArgs &fa, int grid, hipStream_t st, hipEvent_
         if (rm == 1) BRIEF_WIDE_RM(MTWV, 1) else if (rm == 2) BRIEF_WIDE_RM(MTWV, 2) else if (rm == 3) BRIEF_WIDE_RM(MTWV, 3) else BRIEF_WIDE_RM(MTWV, 0)   \
         break;
         switch (mtw) {
+            case 1: BRIEF_WIDE_RM(1, 3) break;   // 3 tiles (TRAIN): all three shared along K by the four waves
             BRIEF_WIDE(2)                    // 5 .. 7 tiles
             BRIEF_WIDE(3) BRIEF_WIDE(4)      // 257 .. 512 features
             BRIEF_WIDE(5) BRIEF_WIDE(6) BRIEF_WIDE(7) BRIEF_WIDE(8)
