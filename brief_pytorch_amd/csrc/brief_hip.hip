@@ -428,13 +428,11 @@ static int launch_fused(const FusedArgs &fa, int grid, hipStream_t st, hipEvent_
     }
     switch (nt) {
         BRIEF_CASE(1) BRIEF_CASE(2) BRIEF_CASE(3) BRIEF_CASE(4) BRIEF_CASE(8)
-    case 7:
     case 12:
     case 16:
         if constexpr (!TRAIN) {      // inference only (their TRAIN steps run on k_lean)
-            const size_t lds7 = sizeof(float) * FusedLds<7, true>::TOTAL, lds12 = sizeof(float) * FusedLds<12, true>::TOTAL, lds16 = sizeof(float) * FusedLds<16, true>::TOTAL;
-            if (nt == 7) launch_timed(k_fused<7, false>, grid, 256, lds7, st, fa, e0, e1);
-            else if (nt == 12) launch_timed(k_fused<12, false>, grid, 256, lds12, st, fa, e0, e1);
+            const size_t lds12 = sizeof(float) * FusedLds<12, true>::TOTAL, lds16 = sizeof(float) * FusedLds<16, true>::TOTAL;
+            if (nt == 12) launch_timed(k_fused<12, false>, grid, 256, lds12, st, fa, e0, e1);
             else launch_timed(k_fused<16, false>, grid, 256, lds16, st, fa, e0, e1);
             break;
         }

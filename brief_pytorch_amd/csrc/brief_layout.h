@@ -59,7 +59,7 @@ BL_HD int brief_nt(const brief_siren_desc &d)
 }
 // Which exact-f32 kernel walks a net of nt tiles (round 4; measured step / decode fractions in profiles/r04_widths.md):
 //   k_fused<NT>  compile-time width, fully unrolled chains, four register arrays per wave: 1, 2, 4 tiles and the 8-tile headline (TRAIN);
-//                1 .. 4, 7 (up to 200 features), 8, 12, 16 tiles (inference: its unrolled chains decode the exact 12- / 16-tile widths 5 % faster).
+//                1 .. 4, 8, 12, 16 tiles (inference: its unrolled chains decode the exact 12- / 16-tile widths 5 % faster).
 //   k_lean       run-time width, rolled chains, one register array per wave, left-over tiles (nt % 4 = 1, 2, 3) shared along K: everything
 //                else — 3 tiles (TRAIN: each of the four waves carries 3 / 4 of a tile pass where k_fused<3>'s fourth wave idled: 4x96 kernel 0.165 -> 0.154 ms,
 //                4x65 0.145 -> 0.136), 5 .. 7 tiles (4x160 trains at 0.61 of the fp32 peak against 0.52, 4x192 0.67 against 0.64) and 9 .. 32 tiles.
@@ -70,10 +70,8 @@ BL_HD bool brief_use_lean(const brief_siren_desc &d, bool train)
 {
     const int nt = brief_nt(d);
     if (train) return (nt >= 5 && nt != 8) || (BRIEF_LEAN3 && nt == 3);
-    // inference, 7 tiles: k_lean's rolled chain walks whole k-tiles (28 steps), k_fused<7, false>'s unrolled one stops at ceil(F / 8) — 4x224
-    // decodes a 256^3 grid in 39.1 ms against 42.5 ms, 4x200 in 39.1 against 38.5
-    if (nt == 7) return d.features > 200;
-    return nt == 5 || nt == 6 || (nt >= 9 && nt != 12 && nt != 16);
+    // (inference, 7 tiles: 4x224 decodes a 256^3 grid in 39.1 ms against k_fused<7, false>'s 42.5, 4x200 in 36.3 against 38.7 since the rolled chain stops at ceil(F / 8) steps)
+    return (nt >= 5 && nt <= 7) || (nt >= 9 && nt != 12 && nt != 16);
 }
 BL_HD int64_t brief_pk_w0(const brief_siren_desc &) { return 0; }
 BL_HD int64_t brief_pk_hidden_stride(const brief_siren_desc &d)
