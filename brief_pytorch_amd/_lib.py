@@ -12,7 +12,9 @@ LIB_PATH = os.environ.get("BRIEF_LIB", os.path.join(_HERE, "libbrief_hip.so"))  
 SRC = os.path.join(_HERE, "csrc", "brief_hip.hip")
 _CSRC = os.path.join(_HERE, "csrc")
 # every file of the translation unit (brief_hip.hip includes the *.inc / *.h beside it) and the public header
-_DEPS = sorted(os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".inc", ".h"))) + [os.path.join(os.path.dirname(_HERE), "include", "brief_hip.h")]
+# (an installation may ship only the prebuilt library, or point BRIEF_LIB at an external build: no csrc/ then, and nothing to rebuild)
+_DEPS = sorted(os.path.join(_CSRC, f) for f in (os.listdir(_CSRC) if os.path.isdir(_CSRC) else []) if f.endswith((".hip", ".inc", ".h"))) \
+    + [os.path.join(os.path.dirname(_HERE), "include", "brief_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
@@ -52,7 +54,7 @@ OUT_F32, OUT_U8, OUT_U16 = 0, 1, 2
 PRECISION = {"fp32": 0, "f32": 0, "bf16": 1, "bf16x3": 2}
 
 EXPORTS = ["brief_version", "brief_last_error", "brief_param_count", "brief_packed_count",
-           "brief_train_workspace_bytes", "brief_siren_repack", "brief_siren_forward", "brief_siren_train_step", "brief_siren_fit_step",
+           "brief_train_workspace_bytes", "brief_siren_repack", "brief_siren_forward", "brief_forward_workspace_bytes", "brief_siren_forward_ws", "brief_siren_train_step", "brief_siren_fit_step",
            "brief_siren_fit", "brief_multi_fit",
            "brief_optim_step", "brief_sample_indices", "brief_sse_u16", "brief_profile_enable", "brief_profile_fused", "brief_deblock_edge", "brief_ssim_u16", "brief_ssim_partial_count",
            "brief_sincos_probe", "brief_cu_count"]
@@ -106,8 +108,8 @@ def lib():
     L = C.CDLL(LIB_PATH)
     dp, gp, bp, vp = C.POINTER(SirenDesc), C.POINTER(GridDesc), C.POINTER(BatchDesc), C.c_void_p
     L.brief_version.restype = C.c_int
-    if L.brief_version() != 120:
-        raise BriefError("libbrief_hip.so is version %d, this binding needs 120 (workspace layout, widths to 1024): rebuild with __graft_entry__.build()" % L.brief_version())
+    if L.brief_version() != 130:
+        raise BriefError("libbrief_hip.so is version %d, this binding needs 130 (brief_siren_forward_ws, widths to 4096): rebuild with __graft_entry__.build()" % L.brief_version())
     L.brief_last_error.restype = C.c_char_p
     L.brief_param_count.restype = C.c_int64
     L.brief_param_count.argtypes = [dp]
@@ -117,6 +119,9 @@ def lib():
     L.brief_train_workspace_bytes.argtypes = [dp, C.c_int64]
     L.brief_siren_repack.argtypes = [dp, vp, vp, vp]
     L.brief_siren_forward.argtypes = [dp, vp, gp, bp, vp, C.c_int, C.c_float, C.c_float, C.c_double, C.c_double, vp]
+    L.brief_forward_workspace_bytes.restype = C.c_int64
+    L.brief_forward_workspace_bytes.argtypes = [dp, C.c_int64]
+    L.brief_siren_forward_ws.argtypes = [dp, vp, gp, bp, vp, C.c_int, C.c_float, C.c_float, C.c_double, C.c_double, vp, C.c_int64, vp]
     L.brief_siren_train_step.argtypes = [dp, vp, gp, bp, C.c_int, C.c_float, C.c_float, vp, vp, vp, vp, C.c_int64, vp]
     L.brief_siren_fit_step.argtypes = [dp, vp, vp, gp, bp, C.c_int, C.c_float, C.c_float, C.c_int, vp, vp,
                                        C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64, vp, vp, vp, C.c_int64, vp]

@@ -45,6 +45,7 @@
 #include "brief_device.inc"     // shared device-side definitions
 #include "brief_fused.inc"      // k_fused
 #include "brief_lean.inc"       // k_lean (run-time widths)
+#include "brief_wide.inc"       // k_wide (widths above 1024 features)
 #include "brief_small.inc"      // k_small, k_small_group
 #include "brief_wgrad.inc"      // k_wgrad
 #include "brief_x3.inc"         // split precision: k_fused_x3, k_wgrad_x3
@@ -73,7 +74,7 @@ static int check_desc(const brief_siren_desc *d)
     if (d->cout < 1 || d->cout > 4) return fail(BRIEF_ERR_INVALID, "data_channel must be 1..4");
     if (d->layers < 2) return fail(BRIEF_ERR_INVALID, "layers must be >= 2");
     if (d->features < 1 || d->features > 32 * BRIEF_MAX_NT)
-        return fail(BRIEF_ERR_INVALID, "features must be 1..1024 on the fused path");
+        return fail(BRIEF_ERR_INVALID, "features must be 1..4096 on the fused path");
     if (d->precision == BRIEF_PREC_BF16 && d->features > 512)
         return fail(BRIEF_ERR_INVALID, "BRIEF_PREC_BF16 supports features <= 512 (wider nets run in BRIEF_PREC_F32)");
     if (d->precision != BRIEF_PREC_F32 && d->precision != BRIEF_PREC_BF16 && d->precision != BRIEF_PREC_BF16X3)
@@ -87,8 +88,46 @@ static int check_desc(const brief_siren_desc *d)
 static const int kProfSlots = 4096;
 static bool g_prof_on = false;
 static int g_prof_n = 0;
-static hipEvent_t g_prof_ev[2 * kProfSlots];
-static bool g_prof_init = false;
+static int g_prof_dev = -1;             // the device brief_profile_enable was called on: only its launches are timed
+
+// ---- per-device library state.  One process per GPU is the deployment, but nothing here may silently assume it: the LDS-size
+// attributes of the kernels, the stream / event pool of brief_multi_fit and the timing events all belong to ONE device, so they
+// are keyed by hipGetDevice() (a process that touches a second device gets its own attributes, streams and events there).
+static const int kMaxDevices = 64;
+static const int kPoolStreams = 8;
+struct DevState {
+    bool pool_init, prof_init;
+    hipStream_t pool[kPoolStreams];
+    hipEvent_t pool_ev[kPoolStreams + 1];
+    hipEvent_t *prof_ev;                // [2 * kProfSlots]
+    int nattr;
+    const void *attr_fn[256];           // kernels whose hipFuncAttributeMaxDynamicSharedMemorySize was set on this device
+    int attr_bytes[256];
+};
+static int current_device()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+    return dev;
+}
+static DevState *dev_state()
+{
+    static DevState *tab[kMaxDevices] = {};
+    const int dev = current_device();
+    if (!tab[dev]) tab[dev] = (DevState *)calloc(1, sizeof(DevState));
+    return tab[dev];
+}
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel, size)
+static int dev_attr_once(const void *fn, int bytes)
+{
+    DevState *ds = dev_state();
+    if (!ds) return fail(BRIEF_ERR_INVALID, "out of host memory");
+    for (int i = 0; i < ds->nattr; ++i)
+        if (ds->attr_fn[i] == fn && ds->attr_bytes[i] >= bytes) return 0;
+    HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    if (ds->nattr < 256) { ds->attr_fn[ds->nattr] = fn; ds->attr_bytes[ds->nattr] = bytes; ++ds->nattr; }
+    return 0;
+}
 
 // compute units of the device the calling thread is on (256 on a whole MI355X; fewer on a partitioned one).  Grids,
 // workspace layout and the start stagger are sized from it, queried once per device.
@@ -146,6 +185,7 @@ static const int g_reduce_sg_small = env_int("BRIEF_REDUCE_SG", 0, 0, 64);      
 // samples one workgroup tile covers: 32 per sample sub-tile; the split-precision TRAIN kernel walks 64-sample tiles
 static int64_t fused_wg_samples(const brief_siren_desc &d, bool train)
 {
+    if (brief_use_wide(d)) return 32;                                                      // k_wide: one 32-sample tile
     if (d.precision == BRIEF_PREC_F32 && brief_use_lean(d, train)) return 32;              // k_lean<1, ...>: one 32-sample tile
     if (!train && d.precision == BRIEF_PREC_F32) return 32 * (4 / brief_wm_infer(brief_nt(d)));      // KCfg<NT, true>
     return brief_wg_samples(brief_nt(d));      // (the split-precision TRAIN kernel deals 32-sample half-tiles too, and walks them in pairs)
@@ -159,6 +199,7 @@ static int fused_grid(const brief_siren_desc &d, int64_t n, bool train)
     const int wpe = g_wg_per_cu_set ? g_wg_per_cu : (d.precision == BRIEF_PREC_BF16X3 && (train || g_x3_decode) ? 2 /* k_fused_x3 */ :
                     (BRIEF_FUSED64 && train && nt == 8 ? (BRIEF_FUSED64 == 1 ? 2 : 3) /* k_lean<2, 2, 8> / k_lean<1, 2, 8> */ : (train ? fused_train_wpe(nt) : (nt > 8 ? 2 : 3))));
     int64_t cap = (int64_t)kCUs * (train && nt > 8 ? 1 : wpe);      // TRAIN > 8 tiles: 512-register kernel, one workgroup per CU
+    if (brief_use_wide(d)) cap = kCUs;                               // k_wide: a 128 KB slab per workgroup
     if (d.precision == BRIEF_PREC_F32 && brief_use_lean(d, train))      // k_lean: what its launch bounds and its LDS image allow
     {
         const int64_t by_lds = (160 * 1024) / (int64_t)(sizeof(float) * lean_lds(1, (nt + 3) / 4, nt).total);
@@ -179,7 +220,7 @@ static FusedPlan fused_plan(const brief_siren_desc &d, int64_t n, bool train)
     const int cap = fused_grid(d, n, train);
     FusedPlan p;
     p.grid = cap; p.pers_wgs = cap; p.pers_tiles = tiles;
-    if (!train || nt > 8 || tiles <= cap) return p;        // decode: millions of tiles, the tail does not matter; > 8 tiles: one workgroup per CU
+    if (!train || nt > 8 || tiles <= cap || brief_use_wide(d)) return p;        // decode: millions of tiles, the tail does not matter; > 8 tiles: one workgroup per CU
     if (g_tail_rounds == 0) return p;
     int64_t rounds = tiles / cap - g_tail_rounds;
     if (rounds < 0) rounds = 0;
@@ -198,6 +239,16 @@ static int wgrad_splits(const brief_siren_desc &d, int64_t n)
     const int64_t nchunks = brief_npad_d(d, n) / 32;
     int64_t s = kWgradBlocks / (hidden * wgrad_nq(brief_nt(d)) * wgrad_nq(brief_nt(d)));
     if (s < 1) s = 1;
+    if (brief_nt(d) > 32) {
+        // above 1024 features one K split already has about as many quadrant blocks as the device has CUs (4x2048: 192): take the
+        // split count whose blocks fill whole rounds best (a slab per split is FP^2 floats, which k_reduce pays for: 2 % per split)
+        const int64_t B = (int64_t)hidden * wgrad_nq(brief_nt(d)) * wgrad_nq(brief_nt(d));
+        double best = 1e30;
+        for (int64_t c = 1; c <= 8; ++c) {
+            const double cost = (double)((c * B + kWgradBlocks - 1) / kWgradBlocks) / (double)c + 0.02 * (double)c;
+            if (cost < best - 1e-9) { best = cost; s = c; }
+        }
+    }
     if (s > nchunks) s = nchunks;
     return (int)s;
 }
@@ -284,6 +335,11 @@ static Ws16 ws16_layout(const brief_siren_desc &d, int64_t n)
 }
 
 struct WsLayout { int64_t z, dd, rec, slabs, table, total; };
+// per-wave records of the fused kernel (k_wide: one workgroup per CU; everything else: up to kRecWgsPerCu)
+static int64_t rec_region_floats(const brief_siren_desc &d)
+{
+    return (int64_t)kCUs * (brief_use_wide(d) ? 1 : kRecWgsPerCu) * 4 * brief_rec_floats(brief_nt(d));
+}
 static WsLayout ws_layout(const brief_siren_desc &d, int64_t n)
 {
     if (d.precision == BRIEF_PREC_BF16) {
@@ -295,9 +351,9 @@ static WsLayout ws_layout(const brief_siren_desc &d, int64_t n)
     const bool small = use_small(d);
     WsLayout w;
     w.z = 0;
-    w.dd = w.z + (small ? 0 : hidden * FP * npad);
+    w.dd = w.z + (small ? 0 : (hidden + (brief_use_wide(d) ? 1 : 0)) * FP * npad);      // k_wide stashes the last sine layer's phase too
     w.rec = w.dd + (small ? 0 : hidden * FP * npad);
-    w.slabs = w.rec + (int64_t)kCUs * kRecWgsPerCu * 4 * brief_rec_floats(nt);
+    w.slabs = w.rec + rec_region_floats(d);
     w.table = w.slabs + hidden * (int64_t)(small ? small_grid(d, n) : wgrad_splits(d, n)) * (FP * FP + FP);
     w.table = (w.table + 3) / 4 * 4;
     w.total = w.table + (small ? kGroupTableFloats : 0);
@@ -362,11 +418,7 @@ static int launch_fused(const FusedArgs &fa, int grid, hipStream_t st, hipEvent_
     if (fa.d.precision == BRIEF_PREC_BF16X3 && (TRAIN || g_x3_decode)) {
         // split precision: the 64-sample walk (k_fused_x3); BRIEF_X3_DECODE=0 evaluates such a net on the f32 forward kernel below
         const size_t lds = sizeof(float) * X3TLds::TOTAL;
-        static bool attr_t64 = false;
-        if (!attr_t64) {
-            HIP_TRY(hipFuncSetAttribute((const void *)k_fused_x3<TRAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_t64 = true;
-        }
+        if (int rc = dev_attr_once((const void *)k_fused_x3<TRAIN>, (int)lds)) return rc;
         launch_timed(k_fused_x3<TRAIN>, grid, 256, lds, st, fa, e0, e1);
         HIP_TRY(hipGetLastError());
         return 0;
@@ -383,16 +435,30 @@ static int launch_fused(const FusedArgs &fa, int grid, hipStream_t st, hipEvent_
         // 2 = k_lean's one-state-array skeleton on 32-sample tiles, three workgroups per CU (k_lean<1, 2, 8>)
         constexpr int SHV = BRIEF_FUSED64 == 1 ? 2 : 1;
         const size_t lds = sizeof(float) * lean_lds(SHV, 2, 8).total;
-        static bool attr_64 = false;
-        if (!attr_64) {
-            HIP_TRY(hipFuncSetAttribute((const void *)k_lean<SHV, 2, 8, TRAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_64 = true;
-        }
+        if (int rc = dev_attr_once((const void *)k_lean<SHV, 2, 8, TRAIN>, (int)lds)) return rc;
         launch_timed(k_lean<SHV, 2, 8, TRAIN>, grid, 256, lds, st, fa, e0, e1);
         HIP_TRY(hipGetLastError());
         return 0;
     }
 #endif
+    if (brief_use_wide(fa.d)) {
+        // k_wide<MTW, TRAIN>: 33 .. 128 feature tiles, output tiles in ceil(nt / 32) passes of 4 waves x MTW, K-slabs staged from the planes
+        const int mtw = wide_mtw(nt);
+        const size_t lds = sizeof(float) * wide_lds(mtw).total;
+        if (!fa.Z) return fail(BRIEF_ERR_WORKSPACE, "widths above 1024 features evaluate through a scratch: call brief_siren_forward_ws with brief_forward_workspace_bytes() bytes");
+#define BRIEF_WIDE_CASE(MTWV)                                                                            \
+    case MTWV:                                                                                           \
+        if (int rc = dev_attr_once((const void *)k_wide<MTWV, TRAIN>, (int)lds)) return rc;              \
+        launch_timed(k_wide<MTWV, TRAIN>, grid, 256, lds, st, fa, e0, e1);                               \
+        break;
+        switch (mtw) {
+            BRIEF_WIDE_CASE(5) BRIEF_WIDE_CASE(6) BRIEF_WIDE_CASE(7) BRIEF_WIDE_CASE(8)
+        default: return fail(BRIEF_ERR_INVALID, "unsupported width");
+        }
+#undef BRIEF_WIDE_CASE
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     if (brief_use_lean(fa.d, TRAIN)) {
         // k_lean<1, MTW, 0>: a run-time number of feature tiles, MTW = ceil(nt / 4) of them per wave (brief_layout.h: brief_use_lean says
         // which widths; inference of exactly 12 or 16 tiles stays on k_fused<12 / 16, false>, whose unrolled chains decode 5 % faster:
@@ -400,14 +466,9 @@ static int launch_fused(const FusedArgs &fa, int grid, hipStream_t st, hipEvent_
         const int mtw = (nt + 3) / 4;
         const int rm = BRIEF_LEAN_RM3 ? (nt & 3) : ((nt & 3) == 3 ? 0 : (nt & 3));      // left-over tiles shared along K by the four waves (brief_lean.inc)
         const size_t lds = sizeof(float) * lean_lds(1, mtw, nt).total;
-        static bool attr_w[9][4] = {};
 #define BRIEF_WIDE_RM(MTWV, RMV)                                                                         \
     {                                                                                                    \
-        if (!attr_w[MTWV][RMV]) {                                                                        \
-            HIP_TRY(hipFuncSetAttribute((const void *)k_lean<1, MTWV, 0, TRAIN, RMV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                        (int)(sizeof(float) * lean_lds(1, MTWV, 4 * MTWV).total)));      \
-            attr_w[MTWV][RMV] = true;                                                                    \
-        }                                                                                                \
+        if (int rc = dev_attr_once((const void *)k_lean<1, MTWV, 0, TRAIN, RMV>, (int)(sizeof(float) * lean_lds(1, MTWV, 4 * MTWV).total))) return rc; \
         launch_timed(k_lean<1, MTWV, 0, TRAIN, RMV>, grid, 256, lds, st, fa, e0, e1);                    \
     }
 #define BRIEF_WIDE(MTWV)                                                                                 \
@@ -448,16 +509,11 @@ template <bool TRAIN>
 static int launch_k16(const FusedArgs &fa, int grid, hipStream_t st, int ns)
 {
     const int nt = brief_nt(fa.d);
-    static bool attr_done[2][2][2][3] = {};
     bool launched = false;
 #define BRIEF_CASE(NTV, COV, NSV)                                                                        \
     if (!launched && nt == NTV && (fa.d.cout == 1) == (COV == 1) && ns == NSV) {                         \
         const size_t lds = sizeof(float) * Cfg16<NTV, NSV>::TOTAL;                                       \
-        bool &done = attr_done[NTV == 16][TRAIN][COV == 1][NSV == 4 ? 2 : NSV - 1];                      \
-        if (!done) {                                                                                     \
-            HIP_TRY(hipFuncSetAttribute((const void *)k16<NTV, TRAIN, COV, NSV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-            done = true;                                                                                 \
-        }                                                                                                \
+        if (int rc = dev_attr_once((const void *)k16<NTV, TRAIN, COV, NSV>, (int)lds)) return rc;          \
         hipLaunchKernelGGL((k16<NTV, TRAIN, COV, NSV>), dim3(grid), dim3(512), lds, st, fa);             \
         launched = true;                                                                                 \
     }
@@ -505,6 +561,12 @@ static int launch_k16_split(FusedArgs &fa, hipStream_t st)
     return 0;
 }
 
+// the live timing is on, has slots left, and was enabled on the device this call runs on
+static bool prof_live()
+{
+    return g_prof_on && g_prof_n < kProfSlots && g_prof_dev == current_device() && dev_state() && dev_state()->prof_init;
+}
+
 static int check_batch(const brief_siren_desc *d, const brief_grid_desc *grid, const brief_batch_desc *b, bool train)
 {
     if (!b || b->n < 1) return fail(BRIEF_ERR_INVALID, "empty batch");
@@ -519,12 +581,31 @@ static int check_batch(const brief_siren_desc *d, const brief_grid_desc *grid, c
 
 extern "C" {
 
+// scratch of an inference launch: two ping-pong activation planes ([FP rows][32 samples]) per workgroup for k_wide, nothing otherwise
+int64_t brief_forward_workspace_bytes(const brief_siren_desc *d, int64_t n)
+{
+    if (check_desc(d) || n < 1) return -1;
+    if (!brief_use_wide(*d)) return 0;
+    return (int64_t)fused_grid(*d, n, false) * 2 * 32 * brief_nt(*d) * 32 * (int64_t)sizeof(float);
+}
+
 int brief_siren_forward(const brief_siren_desc *d, const float *packed, const brief_grid_desc *grid,
                         const brief_batch_desc *batch, void *out, int out_kind,
                         float scale_min, float scale_max, double vmin, double vmax, void *stream)
 {
+    return brief_siren_forward_ws(d, packed, grid, batch, out, out_kind, scale_min, scale_max, vmin, vmax, nullptr, 0, stream);
+}
+
+int brief_siren_forward_ws(const brief_siren_desc *d, const float *packed, const brief_grid_desc *grid,
+                           const brief_batch_desc *batch, void *out, int out_kind,
+                           float scale_min, float scale_max, double vmin, double vmax, void *workspace, int64_t workspace_bytes, void *stream)
+{
     if (int rc = check_desc(d)) return rc;
     if (int rc = check_batch(d, grid, batch, false)) return rc;
+    if (brief_use_wide(*d)) {
+        if (!workspace || workspace_bytes < brief_forward_workspace_bytes(d, batch->n))
+            return fail(BRIEF_ERR_WORKSPACE, "widths above 1024 features evaluate through a scratch of brief_forward_workspace_bytes() bytes");
+    }
     if (!packed || !out) return fail(BRIEF_ERR_INVALID, "null buffer");
     if (out_kind < BRIEF_OUT_F32 || out_kind > BRIEF_OUT_U16) return fail(BRIEF_ERR_INVALID, "bad out_kind");
     FusedArgs fa;
@@ -539,6 +620,7 @@ int brief_siren_forward(const brief_siren_desc *d, const float *packed, const br
     fa.span = (float)(vmax - vmin);
     fa.vmin = (float)vmin;
     fa.stagger_cus = kCUs; fa.stagger = 0;
+    if (brief_use_wide(*d)) fa.Z = (float *)workspace;      // k_wide<.., false>: the ping-pong planes
     if (d->precision == BRIEF_PREC_BF16) return launch_k16_split<false>(fa, (hipStream_t)stream);
     const FusedPlan fp = fused_plan(*d, batch->n, false);
     fa.pers_wgs = fp.pers_wgs; fa.pers_tiles = fp.pers_tiles;
@@ -587,10 +669,11 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
         fa.npad = np; fa.rec = ws + w16.rec; fa.yhat_out = yhat_out; fa.diag = g_diag;
         fa.stagger_cus = kCUs; fa.stagger = g_stagger;
         fa.S16[0] = ws + w16.h; fa.S16[1] = nullptr; fa.S16[2] = ws + w16.dd; fa.S16[3] = ws + w16.x; fa.S16[4] = ws + w16.g;
-        const bool prof16 = g_prof_on && g_prof_n < kProfSlots;
-        if (prof16) HIP_TRY(hipEventRecord(g_prof_ev[2 * g_prof_n], st));
+        const bool prof16 = prof_live();
+        hipEvent_t *pev16 = prof16 ? dev_state()->prof_ev : nullptr;
+        if (prof16) HIP_TRY(hipEventRecord(pev16[2 * g_prof_n], st));
         if (int rc = launch_k16_split<true>(fa, st)) return rc;
-        if (prof16) { HIP_TRY(hipEventRecord(g_prof_ev[2 * g_prof_n + 1], st)); ++g_prof_n; }
+        if (prof16) { HIP_TRY(hipEventRecord(pev16[2 * g_prof_n + 1], st)); ++g_prof_n; }
         Wgrad16Args wa;
         memset(&wa, 0, sizeof(wa));
         const int nsp_s = wgrad16_skinny_splits(*d, batch->n);
@@ -599,9 +682,8 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
         wa.X = (const __bf16 *)(ws + w16.x); wa.G = (const __bf16 *)(ws + w16.g);
         const int nb = nt / 4;
         if (hidden > 0 && nt == 16) {
-            static bool big_attr = false;
             const int lds_big = (int)(sizeof(float) * 4 * W16B_PANEL);
-            if (!big_attr) { HIP_TRY(hipFuncSetAttribute((const void *)k_wgrad16_big, hipFuncAttributeMaxDynamicSharedMemorySize, lds_big)); big_attr = true; }
+            if (int rc = dev_attr_once((const void *)k_wgrad16_big, lds_big)) return rc;
             const int groups8 = (hidden * nsp + 7) / 8 * 8;        // (layer, split) groups padded to whole XCD rounds (see the kernel)
             hipLaunchKernelGGL(k_wgrad16_big, dim3(groups8 * 4), dim3(512), lds_big, st, wa);
         } else if (hidden > 0) {
@@ -680,8 +762,8 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
         plan_only->nb_reduce = nb_hidden + nb_skinny; plan_only->nt = nt; plan_only->hb = small_hb(*d);
         return 0;
     }
-    const bool prof = g_prof_on && g_prof_n < kProfSlots;
-    hipEvent_t pe0 = prof ? g_prof_ev[2 * g_prof_n] : nullptr, pe1 = prof ? g_prof_ev[2 * g_prof_n + 1] : nullptr;
+    const bool prof = prof_live();
+    hipEvent_t pe0 = prof ? dev_state()->prof_ev[2 * g_prof_n] : nullptr, pe1 = prof ? dev_state()->prof_ev[2 * g_prof_n + 1] : nullptr;
     if (small) {
         const int hb = small_hb(*d);
 #define BRIEF_CASE(NTV, HBV)                                                                                        \
@@ -698,7 +780,7 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
         WgradArgs wa;
         memset(&wa, 0, sizeof(wa));
         wa.d = *d; wa.Z = fa.Z; wa.D = fa.D; wa.npad = fa.npad; wa.nsplit = nsplit; wa.slabs = ws + wl.slabs;
-        wa.stamps = ws + wl.rec + (int64_t)kCUs * kRecWgsPerCu * 4 * brief_rec_floats(nt) - 256 * 8 * 8;   // tail of the record region (diagnostics)
+        wa.stamps = ws + wl.rec + rec_region_floats(*d) - 256 * 8 * 8;   // tail of the record region (diagnostics)
         const int blocks = nsplit * (d->layers - 2) * wgrad_nq(nt) * wgrad_nq(nt);
         if (d->precision == BRIEF_PREC_BF16X3) {
             for (int rep = 0; rep < g_wgrad_repeat; ++rep)      // BRIEF_WGRAD_REPEAT (diagnostics): the launch is idempotent
@@ -880,10 +962,6 @@ static int fit_group_step(FitGroup &g, const brief_fit_job *jobs, int64_t k, dou
     return 0;
 }
 
-static const int kPoolStreams = 8;
-static hipStream_t g_pool[kPoolStreams];
-static hipEvent_t g_pool_ev[kPoolStreams + 1];
-static bool g_pool_init = false;
 
 int brief_multi_fit(const brief_fit_job *jobs, int32_t njobs, int64_t steps, void *stream)
 {
@@ -893,11 +971,15 @@ int brief_multi_fit(const brief_fit_job *jobs, int32_t njobs, int64_t steps, voi
     for (int j = 0; j < njobs; ++j)
         if (int rc = fit_job_check(&jobs[j])) return rc;
     if (njobs == 1) return brief_siren_fit(jobs, steps, stream);
-    if (!g_pool_init) {
-        for (int s = 0; s < kPoolStreams; ++s) HIP_TRY(hipStreamCreateWithFlags(&g_pool[s], hipStreamNonBlocking));
-        for (int s = 0; s <= kPoolStreams; ++s) HIP_TRY(hipEventCreateWithFlags(&g_pool_ev[s], hipEventDisableTiming));
-        g_pool_init = true;
+    DevState *ds = dev_state();      // the stream / event pool of the CURRENT device (created on first use there)
+    if (!ds) return fail(BRIEF_ERR_INVALID, "out of host memory");
+    if (!ds->pool_init) {
+        for (int s = 0; s < kPoolStreams; ++s) HIP_TRY(hipStreamCreateWithFlags(&ds->pool[s], hipStreamNonBlocking));
+        for (int s = 0; s <= kPoolStreams; ++s) HIP_TRY(hipEventCreateWithFlags(&ds->pool_ev[s], hipEventDisableTiming));
+        ds->pool_init = true;
     }
+    hipStream_t *g_pool = ds->pool;
+    hipEvent_t *g_pool_ev = ds->pool_ev;
     // Units of work: GROUPS of narrow nets of one kernel variant (k_small_group: one launch per step for up to BRIEF_GROUP_MAX jobs —
     // the many small blocks of a DivideTask, where a launch pair per block and step left the GPU waiting for the host) and single
     // jobs (everything else: their own launches).  Unit u runs on internal stream u mod 8.
@@ -909,7 +991,7 @@ int brief_multi_fit(const brief_fit_job *jobs, int32_t njobs, int64_t steps, voi
     for (int j = 0; j < njobs; ++j) {
         lrs[j] = jobs[j].lr;
         unit_of[j] = -1;
-        if (!use_small(jobs[j].desc) || (g_prof_on && g_prof_n < kProfSlots)) continue;      // (timed runs keep their per-job launches)
+        if (!use_small(jobs[j].desc) || prof_live()) continue;      // (timed runs keep their per-job launches)
         const int nt = brief_nt(jobs[j].desc), hb = small_hb(jobs[j].desc);
         int gi = -1;
         for (int q = ngroups - 1; q >= 0; --q)
@@ -973,12 +1055,17 @@ int brief_optim_step(int kind, float *params, const float *grads, float *state1,
 
 int brief_profile_enable(int on)
 {
-    if (on && !g_prof_init) {
-        for (int i = 0; i < 2 * kProfSlots; ++i) HIP_TRY(hipEventCreate(&g_prof_ev[i]));
-        g_prof_init = true;
+    DevState *ds = dev_state();
+    if (!ds) return fail(BRIEF_ERR_INVALID, "out of host memory");
+    if (on && !ds->prof_init) {
+        ds->prof_ev = (hipEvent_t *)calloc(2 * kProfSlots, sizeof(hipEvent_t));
+        if (!ds->prof_ev) return fail(BRIEF_ERR_INVALID, "out of host memory");
+        for (int i = 0; i < 2 * kProfSlots; ++i) HIP_TRY(hipEventCreate(&ds->prof_ev[i]));
+        ds->prof_init = true;
     }
     g_prof_on = on != 0;
     g_prof_n = 0;
+    g_prof_dev = current_device();
     return 0;
 }
 
@@ -986,10 +1073,13 @@ int brief_profile_fused(double *total_ms, int64_t *launches)
 {
     if (!total_ms || !launches) return fail(BRIEF_ERR_INVALID, "null output");
     double tot = 0.0;
+    DevState *ds = dev_state();
+    if (g_prof_n > 0 && (g_prof_dev != current_device() || !ds || !ds->prof_init))
+        return fail(BRIEF_ERR_INVALID, "brief_profile_fused must be called on the device brief_profile_enable was called on");
     for (int i = 0; i < g_prof_n; ++i) {
         float ms = 0.f;
-        HIP_TRY(hipEventSynchronize(g_prof_ev[2 * i + 1]));
-        HIP_TRY(hipEventElapsedTime(&ms, g_prof_ev[2 * i], g_prof_ev[2 * i + 1]));
+        HIP_TRY(hipEventSynchronize(ds->prof_ev[2 * i + 1]));
+        HIP_TRY(hipEventElapsedTime(&ms, ds->prof_ev[2 * i], ds->prof_ev[2 * i + 1]));
         tot += ms;
     }
     *total_ms = tot;

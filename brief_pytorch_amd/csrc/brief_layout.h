@@ -10,15 +10,15 @@
 #define BL_HD static inline
 #endif
 
-#define BRIEF_MAX_NT 32         // features <= 1024; the width is padded to whole 32-feature tiles only
+#define BRIEF_MAX_NT 128        // features <= 4096 (byte offsets inside one weight block / stash plane are 32-bit); the width is padded to whole 32-feature tiles only
 // per-wave partial record of the fused kernels: dW0[TR local features][4] | dWh[4][TR] | dbh[4] | loss | stamps, TR = 128 local
-// features per wave (4 feature tiles) up to 512 features, 256 (8 tiles) above: brief_rec_tr.  The constants are the TR = 128 case.
+// features per wave (4 feature tiles) up to 512 features, 256 (8 tiles) up to 1024, 32 ceil(nt / 4) above (k_wide): brief_rec_tr.  The constants are the TR = 128 case.
 #define BRIEF_REC_FLOATS 1056
 #define BRIEF_REC_DWH 512
 #define BRIEF_REC_DBH 1024
 #define BRIEF_REC_LOSS 1028
 #define BRIEF_REC_STAMPS 1030
-BL_HD int brief_rec_tr(int nt) { return nt > 16 ? 256 : 128; }
+BL_HD int brief_rec_tr(int nt) { return nt > 32 ? 32 * ((nt + 3) / 4) : (nt > 16 ? 256 : 128); }
 BL_HD int brief_rec_floats(int nt) { return 8 * brief_rec_tr(nt) + 32; }
 
 // --- canonical parameter buffer: W0[F,cin] b0[F] | (W_l[F,F] b_l[F]) x (L-2) | Wh[cout,F] bh[cout]
@@ -66,9 +66,12 @@ BL_HD int brief_nt(const brief_siren_desc &d)
 #ifndef BRIEF_LEAN3
 #define BRIEF_LEAN3 1      // 3-tile nets (65 .. 96 features) TRAIN on k_lean, their three tiles shared along K by the four waves (0: k_fused<3>, whose fourth wave idles)
 #endif
+//   k_wide       33 .. 128 tiles (1025 .. 4096 features): k_lean's rolled chain on K-slabs staged from the stash planes, output tiles in passes (brief_wide.inc)
+BL_HD bool brief_use_wide(const brief_siren_desc &d) { return d.precision == BRIEF_PREC_F32 && (d.features + 31) / 32 > 32; }
 BL_HD bool brief_use_lean(const brief_siren_desc &d, bool train)
 {
     const int nt = brief_nt(d);
+    if (nt > 32) return false;
     if (train) return (nt >= 5 && nt != 8) || (BRIEF_LEAN3 && nt == 3);
     // (inference, 7 tiles: 4x224 decodes a 256^3 grid in 39.1 ms against k_fused<7, false>'s 42.5, 4x200 in 36.3 against 38.7 since the rolled chain stops at ceil(F / 8) steps)
     return (nt >= 5 && nt <= 7) || (nt >= 9 && nt != 12 && nt != 16);

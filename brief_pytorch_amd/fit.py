@@ -126,7 +126,10 @@ class Fitter:
     def max_steps_per_call(self, share=1):
         """steps one C-ABI call may cover; `share`: how many fitters with index streams split the budget (MultiFitter: every
         co-trained block keeps its run of index sets alive until the call returns, so the budget is divided, not multiplied)"""
-        return max(1, self.INDEX_STREAM_BYTES // max(int(share), 1) // (8 * self.n)) if self.index_stream is not None else 1 << 62
+        if self.index_stream is None:
+            return 1 << 62
+        cap = max(1, self.INDEX_STREAM_BYTES // max(int(share), 1) // (8 * self.n))
+        return min(cap, int(getattr(self.index_stream, "steps_per_call", cap)))      # (a host-drawn stream asks for short runs: the next one is drawn while this one trains)
 
     def _index_batch(self, t_first, steps):
         """the index sets of steps t_first .. t_first + steps - 1 as one device tensor [steps, n] (draw order = step order,

@@ -236,6 +236,18 @@ class NFGR:
                 index_stream = _CubeIndexStream(dims, cl, C_.sampler.cube_count, self.device, generator=gen)
         elif C_.sampler.name != "randompoint":
             raise NotImplementedError(C_.sampler.name)
+        # Compress.sampler.rng (an extra key, default "philox"): which generator draws the randompoint indices.  "philox" — in the fused
+        # kernel, counter-based, keyed by (seed, step): statistically the reference's sampler, not its stream.  "torch" — the reference's
+        # own draws (main.py:154-163: torch.randint(0, pop, (sample_size,)) on the CPU generator, once per step, behind reproduc(seed)
+        # and the net's init draws), fed to the fit loop as a device-resident index stream: `python main.py -p ...` then touches the
+        # voxels the reference touches, step for step.
+        rng_mode = str(C_.sampler.get("rng", "philox")).lower()
+        if rng_mode not in ("philox", "torch"):
+            raise ValueError("Compress.sampler.rng must be 'philox' or 'torch' (got %r)" % rng_mode)
+        if rng_mode == "torch" and sampler == "randompoint" and index_stream is None:
+            gen = torch.Generator()
+            gen.set_state(torch.get_rng_state())      # a private fork, as for the windowed cube sampler above
+            index_stream = _PointIndexStream(int(np.prod(dims)), int(C_.sampler.sample_size), self.device, generator=gen)
         n_step = C_.sampler.sample_size if index_stream is None else index_stream.n
         fit = Fitter(phi, tgt, dims, _coords_range(C_.coords_mode), weights=wts, sampler=sampler, sample_size=n_step,
                      optimizer=C_.optimizer_name_phi, lr=C_.lr_phi, scheduler=config.to_plain(C_.lr_scheduler_phi),
@@ -704,6 +716,31 @@ def _append_csv(path, row):
         if new:
             w.writerow(row.keys())
         w.writerow([row[k] for k in row.keys()])
+
+
+class _PointIndexStream:
+    """RandompointSampler's own index draws (main.py:154-163): `torch.randint(0, pop_size, (sample_size,))` on the CPU generator, one call
+    per optimizer step (NFGR.prepare_fit hands over a private fork of the global generator taken behind the net's init draws, which is where
+    the reference's loop finds it).  Selected by Compress.sampler.rng: torch; the default sampler draws Philox indices inside the fused kernel.
+    The draws of a run of steps travel to the device as ONE [steps, n] tensor (brief_fit_job.idx_stride): brief_siren_fit only enqueues, so
+    the host draws the next run while the device works through the current one (`steps_per_call` bounds the run: 64 steps of 100 000
+    indices are 30 ms of mt19937 draws and 51 MB).  Pinned: tests/golden/trace.npz (pt_idx)."""
+
+    steps_per_call = 64
+
+    def __init__(self, pop, n, device, generator=None):
+        self.pop, self.n = int(pop), int(n)
+        self.gen = generator                 # None: the global generator, as the reference
+        self.device = device
+
+    def __call__(self, t):
+        return torch.randint(0, self.pop, (self.n,), generator=self.gen).to(self.device)
+
+    def batch(self, t_first, steps):
+        host = torch.empty((int(steps), self.n), dtype=torch.int64)
+        for k in range(int(steps)):          # one randint call per step: the reference's consumption of the generator, draw for draw
+            host[k] = torch.randint(0, self.pop, (self.n,), generator=self.gen)
+        return host.to(self.device)
 
 
 class _CubeIndexStream:

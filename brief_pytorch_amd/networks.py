@@ -8,6 +8,7 @@ torch.autograd MLP and no CPU fallback.
 """
 import copy
 import ctypes as C
+import logging
 import math
 from collections import OrderedDict
 
@@ -115,7 +116,7 @@ class SIREN:
 
     def __init__(self, coords_channel=3, data_channel=1, features=256, layers=5, w0=30, res=False,
                  output_act=False, device=None, precision="fp32", **kwargs):
-        """precision: 'fp32' (exact f32 MFMA, the parity path, features <= 1024), 'bf16' (hidden GEMMs on the bf16 matrix pipe,
+        """precision: 'fp32' (exact f32 MFMA, the parity path, features <= 4096), 'bf16' (hidden GEMMs on the bf16 matrix pipe,
         f32 master weights: the MI355X counterpart of Compress.half; include/brief_hip.h: BRIEF_PREC_BF16, features <= 512) or 'bf16x3'
         (split precision inside the fp32 parity bands, BRIEF_PREC_BF16X3, features <= 256; training AND inference run the split chains)."""
         if res:
@@ -138,6 +139,7 @@ class SIREN:
         self._autograd = False
         self._anchor = None
         self._ws = None
+        self._fws = None
         self._loss = None
         net, off = [], 0
         for (o, i) in self._shapes:
@@ -193,7 +195,7 @@ class SIREN:
             self.params = self.params.to(device)
             self.grads = None
             self.packed = None
-            self._ws = None
+            self._ws = self._fws = None
             self._stale = True
         return self
 
@@ -208,13 +210,14 @@ class SIREN:
             self.precision = precision
             self.desc.precision = _lib.PRECISION[precision]
             self.packed = None          # the fragment-ordered copy has another size and content
-            self._ws = None
+            self._ws = self._fws = None
             self._stale = True
         return self
 
     def float(self):
         """nn.Module.float() as the reference's low-precision loop uses it (main.py:398: back to fp32 for the update)"""
-        return self._set_precision(getattr(self, "_float_precision", self.precision))
+        # (the mode half() recorded is consumed here: after a _set_precision / to() round trip a later float() cannot restore a stale one)
+        return self._set_precision(self.__dict__.pop("_float_precision", self.precision))
 
     def half(self):
         """nn.Module.half() as the reference uses it (main.py:212, 287-288, 389): its fp16 mode.  The MI355X counterpart is the
@@ -223,6 +226,10 @@ class SIREN:
         kernels and stay exact."""
         if self.precision != "bf16":
             self._float_precision = self.precision
+        if self.features > 512 and not getattr(SIREN, "_warned_half_wide", False):
+            SIREN._warned_half_wide = True
+            logging.warning("SIREN.half(): no bf16 kernels above 512 features (this net has %d): it stays in exact fp32; "
+                            "callers that round coordinates / outputs to fp16 around it get the I/O rounding only", self.features)
         return self._set_precision("bf16" if self.features <= 512 else self.precision)
 
     def eval(self):
@@ -291,9 +298,22 @@ class SIREN:
         if n == 0:
             return out.view(*lead, self.data_channel)
         b = _lib.BatchDesc(c.data_ptr(), None, None, None, 0, n, 0, 0, 0)
-        _lib.check(_lib.lib().brief_siren_forward(C.byref(self.desc), _lib.ptr(self.packed), None, C.byref(b), _lib.ptr(out),
-                                                  _lib.OUT_F32, 0.0, 1.0, 0.0, 1.0, _lib.stream_ptr()))
+        ws, ws_bytes = self._forward_scratch(n)
+        _lib.check(_lib.lib().brief_siren_forward_ws(C.byref(self.desc), _lib.ptr(self.packed), None, C.byref(b), _lib.ptr(out),
+                                                     _lib.OUT_F32, 0.0, 1.0, 0.0, 1.0, ws, ws_bytes, _lib.stream_ptr()))
         return out.view(*lead, self.data_channel)
+
+    def _forward_scratch(self, n):
+        """(pointer, bytes) of the inference scratch brief_siren_forward_ws wants: nothing up to 1024 features, two ping-pong
+        activation planes per workgroup above (include/brief_hip.h); allocated once, kept"""
+        need = _lib.lib().brief_forward_workspace_bytes(C.byref(self.desc), int(n))
+        if need < 0:
+            raise _lib.BriefError(_lib.lib().brief_last_error().decode())
+        if need == 0:
+            return None, 0
+        if self._fws is None or self._fws.numel() * 4 < need:
+            self._fws = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.params.device)
+        return _lib.ptr(self._fws), self._fws.numel() * 4
 
     def __call__(self, coords):
         return self.forward(coords)
@@ -313,9 +333,10 @@ class SIREN:
             out = torch.empty((count, self.data_channel), dtype=dt, device=self.params.device)
         g = self._grid(dims, lo, hi)
         b = _lib.BatchDesc(None, None, None, None, int(offset), count, 0, 0, 0)
-        _lib.check(_lib.lib().brief_siren_forward(C.byref(self.desc), _lib.ptr(self.packed), C.byref(g), C.byref(b), _lib.ptr(out),
-                                                  kind, float(scale[0]), float(scale[1]), float(vrange[0]), float(vrange[1]),
-                                                  _lib.stream_ptr()))
+        ws, ws_bytes = self._forward_scratch(count)
+        _lib.check(_lib.lib().brief_siren_forward_ws(C.byref(self.desc), _lib.ptr(self.packed), C.byref(g), C.byref(b), _lib.ptr(out),
+                                                     kind, float(scale[0]), float(scale[1]), float(vrange[0]), float(vrange[1]),
+                                                     ws, ws_bytes, _lib.stream_ptr()))
         return out
 
     def train_step(self, n, targets, idx=None, coords=None, weights=None, grid=None, offset=0,

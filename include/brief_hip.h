@@ -18,12 +18,12 @@
 extern "C" {
 #endif
 
-#define BRIEF_VERSION 120 /* 0.1.2: features up to 1024 (k_lean), narrow-net workspaces end in a group table (brief_multi_fit trains up to 64 narrow nets per launch
-                           * pair); struct layouts as in 0.1.1 (brief_fit_job with lr_table, beta1_table, idx_stride) */
+#define BRIEF_VERSION 130 /* 0.1.3: features up to 4096 (k_wide; brief_siren_forward_ws + brief_forward_workspace_bytes: inference above 1024 features needs a
+                           * scratch), library state per device; struct layouts as in 0.1.1 (brief_fit_job with lr_table, beta1_table, idx_stride) */
 
 typedef enum {
     BRIEF_OK = 0,
-    BRIEF_ERR_INVALID = -1,      /* bad argument / unsupported configuration (e.g. res=True, F > 1024) */
+    BRIEF_ERR_INVALID = -1,      /* bad argument / unsupported configuration (e.g. res=True, F > 4096) */
     BRIEF_ERR_LAUNCH = -2,       /* HIP launch / runtime error */
     BRIEF_ERR_WORKSPACE = -3     /* workspace too small */
 } brief_status;
@@ -34,8 +34,8 @@ typedef struct {
     int32_t cin;         /* 2 | 3 */
     int32_t cout;        /* 1 .. 4 */
     int32_t layers;      /* >= 2 */
-    int32_t features;    /* 1 .. 1024 for BRIEF_PREC_F32 (padded internally to whole 32-feature tiles; SIREN.calc_features, utils/Networks.py:299-314,
-                          * has no width limit: the shipped default.yaml on a 512^3 uint16 volume solves to 527), 1 .. 512 for BRIEF_PREC_BF16,
+    int32_t features;    /* 1 .. 4096 for BRIEF_PREC_F32 (padded internally to whole 32-feature tiles; SIREN.calc_features, utils/Networks.py:299-314,
+                          * has no width limit: the shipped default.yaml solves to 527 on a 512^3 uint16 volume and to 1495 on a 1024^3 one), 1 .. 512 for BRIEF_PREC_BF16,
                           * 1 .. 256 for BRIEF_PREC_BF16X3 */
     float w0_first;
     float w0_hidden;
@@ -107,6 +107,13 @@ int brief_siren_repack(const brief_siren_desc *d, const float *params, float *pa
 int brief_siren_forward(const brief_siren_desc *d, const float *packed, const brief_grid_desc *grid,
                         const brief_batch_desc *batch, void *out, int out_kind,
                         float scale_min, float scale_max, double vmin, double vmax, void *stream);
+/* The same with a caller-provided scratch.  Nets of more than 1024 features keep no layer in LDS whole: their activations travel
+ * through two ping-pong planes per workgroup in `workspace` (brief_forward_workspace_bytes(d, n) bytes, 0 up to 1024 features, where
+ * workspace may be NULL); brief_siren_forward refuses such a net with BRIEF_ERR_WORKSPACE. */
+int64_t brief_forward_workspace_bytes(const brief_siren_desc *d, int64_t n);
+int brief_siren_forward_ws(const brief_siren_desc *d, const float *packed, const brief_grid_desc *grid,
+                           const brief_batch_desc *batch, void *out, int out_kind,
+                           float scale_min, float scale_max, double vmin, double vmax, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* zero_grad + forward + loss + backward of main.py:385-396 for one batch.
  * grads: canonical packed layout, fully overwritten.  loss_out: one float (mean loss).

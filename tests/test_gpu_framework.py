@@ -69,6 +69,40 @@ def test_singletask_matches_reference_run(tmp_path, golden):
     assert np.median(d) < 40
 
 
+def test_randompoint_fit_reproduces_the_reference_trace_from_the_seed_alone(tmp_path, golden):
+    """Compress.sampler.rng: torch: with the reference's seed and nothing else — no recorded index stream — the
+    fit through NFGR.prepare_fit touches the voxels the reference's RandompointSampler touched (main.py:126-163, 653-661) and its
+    50-step loss trace is the reference's to 1e-4, its final weights to 5e-5 (tests/golden/trace.npz: seed 42, 4 x 32, 1 000 samples)."""
+    g = golden("trace")
+    vol = g["pt_vol"]
+    opt = _opt(tmp_path, 50, "none", 4.0 * SIREN.calc_param_count(3, 1, 32, 4))
+    cf = opt.CompressFramework
+    cf.Module.phi.layers = 4
+    cf.Compress.sampler.name = "randompoint"
+    cf.Compress.sampler.sample_size = 1000
+    cf.Compress.sampler.rng = "torch"
+    torch.manual_seed(42)                                   # reproduc(seed 42), as in the golden run
+    fw = NFGR(cf, Log=None)
+    ctx = fw.prepare_fit(str(tmp_path / "vol.tif"), data=vol, logdir=str(tmp_path))
+    phi = ctx["phi"]
+    for l in range(4):
+        assert np.array_equal(phi.net[l][0].weight.data.cpu().numpy(), g["pt_init_w%d" % l])
+    losses = ctx["fit"].run(50, log=True).cpu().numpy().astype(np.float64)
+    assert np.max(np.abs(losses - g["pt_losses"]) / g["pt_losses"]) < 1e-4
+    for l in range(4):
+        assert np.max(np.abs(phi.net[l][0].weight.data.cpu().numpy() - g["pt_final_w%d" % l])) < 5e-5
+    # the default (Philox, in-kernel) draws other voxels: same statistics, another trace
+    cf.Compress.sampler.rng = "philox"
+    torch.manual_seed(42)
+    ctx2 = NFGR(cf, Log=None).prepare_fit(str(tmp_path / "vol.tif"), data=vol, logdir=str(tmp_path))
+    other = ctx2["fit"].run(50, log=True).cpu().numpy().astype(np.float64)
+    assert np.max(np.abs(other - g["pt_losses"]) / g["pt_losses"]) > 1e-3
+    assert abs(other[-1] - g["pt_losses"][-1]) / g["pt_losses"][-1] < 0.5
+    with pytest.raises(ValueError):
+        cf.Compress.sampler.rng = "mt"
+        NFGR(cf, Log=None).prepare_fit(str(tmp_path / "vol.tif"), data=vol, logdir=str(tmp_path))
+
+
 @pytest.mark.parametrize("L,F", [(5, 256), (4, 40), (3, 300), (3, 600)])
 def test_reference_loop_body_runs_on_the_module(L, F):
     """the reference's own loop body (main.py:385-400: zero_grad, forward, loss_func, backward, torch.optim step,

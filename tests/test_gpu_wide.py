@@ -163,7 +163,7 @@ def test_wide_is_bit_reproducible_and_refuses_what_it_cannot_run():
     m.train_step(5000, y, coords=x)
     assert torch.equal(g1, m.grads)
     L = _lib.lib()
-    assert L.brief_param_count(C.byref(_lib.SirenDesc(3, 1, 5, 1025, 20.0, 30.0, 0, 0))) == -1 and b"1024" in L.brief_last_error()
+    assert L.brief_param_count(C.byref(_lib.SirenDesc(3, 1, 5, 4097, 20.0, 30.0, 0, 0))) == -1 and b"4096" in L.brief_last_error()
     assert L.brief_param_count(C.byref(_lib.SirenDesc(3, 1, 5, 600, 20.0, 30.0, 0, 1))) == -1 and b"BF16" in L.brief_last_error()
     assert L.brief_param_count(C.byref(_lib.SirenDesc(3, 1, 5, 600, 20.0, 30.0, 0, 2))) == -1
 

@@ -1,0 +1,157 @@
+"""Widths above 1024 features (VERDICT round 4 "missing" #1): SIREN.calc_features (utils/Networks.py:299-314,
+main.py:248-264) has no upper bound — the shipped opt/SingleTask/default.yaml (ratio 80) on a 1024^3 uint16 volume, a size
+BASELINE.json names, solves to F = 1495.  These nets run on k_wide<MTW> (csrc/brief_wide.inc: output tiles in passes, K-slabs staged
+from the stash planes) + k_wgrad<0, QT>, held to the same oracle bands as every other fp32 width: forward 2e-5 of max|y|, loss 1e-5,
+every gradient tensor 1e-4 of its max-abs; the fused optimizer path bit-identical to the separate entry points."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from brief_pytorch_amd import _lib
+from brief_pytorch_amd.fit import Fitter
+from brief_pytorch_amd.networks import SIREN
+from oracle import oracle as O
+
+from .test_gpu_wide import check_grads, make_net, relerr
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+# tile counts 35 (2 passes x 5 slots, wave 3 short), 47 (the default.yaml width on 1024^3: 2 x 6), 57 (2 x 8, short), 64 (2 x 8 exact),
+# 66 (3 passes x 6), 94 (3 x 8), 128 (4 x 8: the maximum); two-channel coordinates, RGB outputs, no hidden layer, output activation
+@pytest.mark.parametrize("L,F,cin,cout,n", [(5, 1100, 3, 1, 257), (5, 1495, 3, 1, 100), (3, 1800, 2, 3, 65), (4, 2048, 3, 1, 130), (3, 2100, 3, 1, 33),
+                                             (3, 3000, 3, 1, 31), (3, 4096, 3, 1, 40), (2, 1500, 3, 1, 77), (3, 1025, 3, 2, 9000)])
+def test_forward_above_1024_vs_oracle(L, F, cin, cout, n):
+    m, d, p = make_net(L, F, 20.0, cin, cout, seed=L * 100 + F)
+    x = np.random.default_rng(F).uniform(-1, 1, size=(n, cin)).astype(np.float32)
+    y = m.forward(torch.from_numpy(x).to(DEV)).cpu().numpy()
+    assert y.shape == (n, cout)
+    assert relerr(y, O.forward(d, p, x)) < 2e-5
+
+
+@pytest.mark.parametrize("L,F,cin,cout,n,oa", [(5, 1100, 3, 1, 300, False), (5, 1495, 3, 1, 200, False), (4, 2048, 3, 1, 130, False),
+                                                (3, 1800, 2, 3, 100, False), (4, 1200, 3, 1, 333, True), (3, 2100, 3, 2, 70, False),
+                                                (3, 4096, 3, 1, 40, False), (2, 1500, 3, 1, 129, False), (3, 1056, 3, 1, 8300, False)])
+def test_train_step_above_1024_vs_oracle(L, F, cin, cout, n, oa):
+    m, d, p = make_net(L, F, 20.0, cin, cout, oa, seed=L * 10 + F)
+    rng = np.random.default_rng(F + n)
+    x = rng.uniform(-1, 1, size=(n, cin)).astype(np.float32)
+    y = rng.uniform(0, 100, size=(n, cout)).astype(np.float32)
+    w = np.where(rng.uniform(size=(n, cout)) < 0.5, 0.25, 1.0).astype(np.float32)
+    loss, yhat = m.train_step(n, torch.from_numpy(y).to(DEV), coords=torch.from_numpy(x).to(DEV),
+                              weights=torch.from_numpy(w).to(DEV), thr=30.0, want_yhat=True)
+    lo, go, _, _ = O.loss_grad(d, p, x, y, w, 0, 30.0, 0.01)
+    assert relerr(yhat.cpu().numpy(), O.forward(d, p, x)) < 2e-5
+    assert abs(loss.item() - lo) / abs(lo) < 1e-5
+    check_grads(m, d, go)
+
+
+@pytest.mark.parametrize("F", [1100, 1495, 2048])
+def test_above_1024_grid_sampled_step_fused_optimizer_and_decode(F):
+    """the product's own sampler (in-kernel Philox indices, synthesised coordinates) on a 24x32x40 grid, L = 5: one step against the
+    oracle on the same indices; the fused optimizer entry point (brief_siren_fit) bit-identical to train_step + optim_step + repack;
+    two identical runs give identical bits; the decode of the whole grid (uint16 epilogue included) against the oracle"""
+    dims = (24, 32, 40)
+    pop = int(np.prod(dims))
+    n = 300
+    from brief_pytorch_amd.synthetic import make_volume
+    tv = O.normalize(make_volume(dims, seed=F))[0].reshape(-1, 1).astype(np.float32)
+    tvd = torch.from_numpy(tv).to(DEV)
+    m, d, p = make_net(5, F, 20.0, seed=F)
+    coords = O.grid_coords(dims)
+    idx = torch.empty(n, dtype=torch.int64, device=DEV)
+    _lib.check(_lib.lib().brief_sample_indices(_lib.ptr(idx), n, pop, 42, 1, _lib.stream_ptr()))
+    ii = idx.cpu().numpy()
+    loss, _ = m.train_step(n, tvd, idx=idx, grid=(dims, -1.0, 1.0))
+    lo, go, _, _ = O.loss_grad(d, p, coords[ii], tv[ii])
+    assert abs(loss.item() - lo) / abs(lo) < 1e-5
+    check_grads(m, d, go)
+    # ---- fused optimizer == separate calls, bit for bit; and run to run
+    m2, _, _ = make_net(5, F, 20.0, seed=F)
+    s1d, s2d = torch.zeros_like(m2.params), torch.zeros_like(m2.params)
+    for t in range(1, 4):
+        _lib.check(_lib.lib().brief_sample_indices(_lib.ptr(idx), n, pop, 42, t, _lib.stream_ptr()))
+        m2.train_step(n, tvd, idx=idx, grid=(dims, -1.0, 1.0))
+        _lib.check(_lib.lib().brief_optim_step(0, _lib.ptr(m2.params), _lib.ptr(m2.grads), _lib.ptr(s1d), _lib.ptr(s2d), m2.params.numel(),
+                                               1e-3, 0.9, 0.999, 1e-8, t, _lib.stream_ptr()))
+        m2._stale = True
+    runs = []
+    for _ in range(2):
+        m3, _, _ = make_net(5, F, 20.0, seed=F)
+        Fitter(m3, tvd, dims, sampler="randompoint", sample_size=n, seed=42).run(3)
+        runs.append(m3)
+    assert torch.equal(m2.params, runs[0].params)
+    assert torch.equal(runs[0].params, runs[1].params) and torch.equal(runs[0].packed, runs[1].packed)
+    # ---- decode of the whole grid: f32 against the oracle, and the fused uint16 epilogue against the host rule on the kernel's own yhat
+    m0, _, _ = make_net(5, F, 20.0, seed=F)
+    yd = m0.decode_grid(dims).cpu().numpy().reshape(-1, 1)
+    assert relerr(yd, O.forward(d, p, coords)) < 2e-5
+    u16 = m0.decode_grid(dims, out_kind="u16", scale=(-1.0, 1.0), vrange=(0.0, 65535.0)).cpu().numpy().reshape(-1)
+    t_ = np.clip((yd.reshape(-1) - np.float32(-1.0)) / np.float32(2.0), 0, 1).astype(np.float32)
+    assert np.array_equal(u16, (t_ * np.float32(65535.0) + np.float32(0.0)).astype(np.float32).astype(np.int64).astype(np.uint16))
+    # chunked decode == one call (the scratch planes are per workgroup, whatever the tile walk)
+    half = pop // 2 + 7
+    two = torch.cat([m0.decode_grid(dims, offset=0, count=half), m0.decode_grid(dims, offset=half)]).cpu().numpy()
+    assert np.array_equal(two, yd)
+
+
+def test_forward_above_1024_needs_its_scratch():
+    """brief_siren_forward (no workspace) refuses such a net loudly; brief_siren_forward_ws with too small a scratch too"""
+    m, d, p = make_net(3, 1100, seed=3)
+    m.sync_packed()
+    x = torch.zeros(64, 3, device=DEV)
+    out = torch.empty(64, 1, device=DEV)
+    b = _lib.BatchDesc(x.data_ptr(), None, None, None, 0, 64, 0, 0, 0)
+    L = _lib.lib()
+    rc = L.brief_siren_forward(C.byref(m.desc), _lib.ptr(m.packed), None, C.byref(b), _lib.ptr(out), _lib.OUT_F32, 0.0, 1.0, 0.0, 1.0, _lib.stream_ptr())
+    assert rc == -3 and b"scratch" in L.brief_last_error()
+    small = torch.empty(16, device=DEV)
+    rc = L.brief_siren_forward_ws(C.byref(m.desc), _lib.ptr(m.packed), None, C.byref(b), _lib.ptr(out), _lib.OUT_F32, 0.0, 1.0, 0.0, 1.0,
+                                  _lib.ptr(small), 64, _lib.stream_ptr())
+    assert rc == -3
+    assert L.brief_forward_workspace_bytes(C.byref(m.desc), 64) == 2 * 2 * 35 * 32 * 32 * 4
+
+
+def test_cli_default_yaml_on_a_1024_cube_solves_to_1495_features_and_runs(tmp_path):
+    """python main.py -p opt/SingleTask/default.yaml on a 1024^3 uint16 volume (memory-mapped .npy): ratio 80 gives 26.8 MB =
+    6.7 M parameters, which SIREN.calc_features solves to F = 1495 for five layers — 47 feature tiles, above round 4's ceiling of 32.
+    Shortened to 60 steps (37 ms each) + the decode of the 2^30 voxels (about two minutes of f32 MFMA work); everything else is the shipped file."""
+    from brief_pytorch_amd import config
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    opt = config.load(os.path.join(root, "opt", "SingleTask", "default.yaml"))
+    opt.Dataset.data_path = str(tmp_path / "dataset" / "synthetic_1024.npy")
+    from brief_pytorch_amd.synthetic import make_volume_torch
+    os.makedirs(str(tmp_path / "dataset"))
+    from brief_pytorch_amd.tool import save_img
+    save_img(opt.Dataset.data_path, make_volume_torch((1024, 1024, 1024), seed=42, device="cuda").cpu().numpy())      # 2 GiB, generated on the device
+    torch.cuda.empty_cache()
+    assert os.path.getsize(opt.Dataset.data_path) - 1024 ** 3 * 2 < 1024
+    opt.CompressFramework.Compress.max_steps = 60
+    opt.CompressFramework.Compress.checkpoints = "none"
+    opt.CompressFramework.Decompress.mip = False
+    opt.CompressFramework.Decompress.ssim = False
+    opt.CompressFramework.Decompress.keep_decompressed = False
+    opt.Log.outputs_dir = str(tmp_path / "outputs")
+    opt.Log.time = False
+    y = str(tmp_path / "cli1024.yaml")
+    config.save(opt, y)
+    r = subprocess.run([sys.executable, os.path.join(root, "main.py"), "-p", y, "-g", "0"], capture_output=True, text=True, timeout=1100)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+    run = os.path.join(str(tmp_path / "outputs"), "single")
+    side = config.load(os.path.join(run, "steps60", "compressed", "sideinfos.yaml"))
+    assert side["phi_features"] == 1495 and list(side["data_shape"]) == [1024, 1024, 1024, 1]
+    mod = os.path.join(run, "steps60", "compressed", "module")
+    assert os.path.getsize(os.path.join(mod, "weight-2-1495-1495")) == 1495 * 1495 * 4
+    total = sum(os.path.getsize(os.path.join(mod, f)) for f in os.listdir(mod))
+    assert abs(total - 1024 ** 3 * 2 / 80) / (1024 ** 3 * 2 / 80) < 0.01                # the ratio-80 budget
+    rows = open(os.path.join(run, "performance.csv")).read().strip().splitlines()
+    head, vals = rows[0].split(","), rows[1].split(",")
+    psnr = float(vals[head.index("psnr")])
+    print("default.yaml on 1024^3: F = 1495, 60 steps, psnr %.2f dB" % psnr)
+    assert psnr > 25.0                                                                   # 60 steps only: a floor, not a quality claim

@@ -186,6 +186,28 @@ def test_windowed_cube_sampler_index_stream_matches_the_reference(golden):
     assert a.numel() == st.n and int(a.max()) < int(np.prod(dims))
 
 
+def test_torch_rng_point_sampler_reproduces_the_reference_stream_from_the_seed_alone(golden):
+    """Compress.sampler.rng: torch — RandompointSampler's own draws (main.py:154-163: torch.randint(0, pop, (sample_size,)) on the CPU
+    generator, once per step, behind reproduc(seed) and the net's init draws).  tests/golden/trace.npz recorded the reference's index
+    sets of 50 steps (seed 42, 4 x 32 net, 12 x 20 x 28 volume, 1 000 samples per step): the stream must BE them, draw for draw,
+    whether it is asked step by step or for runs of steps at once."""
+    from brief_pytorch_amd.framework import _PointIndexStream
+    g = golden("trace")
+    pop = int(np.prod(g["pt_vol"].shape[:3]))
+    for how in ("steps", "runs"):
+        torch.manual_seed(42)                               # reproduc(opt.Reproduc), main.py:653-661
+        m = SIREN(features=32, layers=4, w0=20)             # prepare_module consumes the generator first
+        assert np.array_equal(m.net[0][0].weight.data.numpy(), g["pt_init_w0"])
+        gen = torch.Generator()
+        gen.set_state(torch.get_rng_state())                # NFGR.prepare_fit's private fork
+        st = _PointIndexStream(pop, 1000, "cpu", generator=gen)
+        if how == "steps":
+            got = np.stack([st(t + 1).numpy() for t in range(50)])
+        else:
+            got = np.concatenate([st.batch(1, 7).numpy(), st.batch(8, 43).numpy()])
+        assert np.array_equal(got, g["pt_idx"]), how
+
+
 @pytest.mark.parametrize("kw", [dict(base_lr=1e-4, max_lr=1e-3, step_size_up=7), dict(base_lr=1e-4, max_lr=2e-3, step_size_up=5, step_size_down=9, mode="triangular2"),
                                 dict(base_lr=2e-4, max_lr=1e-3, step_size_up=4, mode="exp_range", gamma=0.97),
                                 dict(base_lr=1e-4, max_lr=1e-3, step_size_up=6, cycle_momentum=False)])
