@@ -49,12 +49,16 @@ DTYPES = {"fp32": "f32", "bf16": "bf16", "bf16x3": "bf16x3"}
 
 
 def train_on_lean(F):
-    """csrc/brief_layout.h: brief_use_lean(train): 3 tiles and every tile count from 5 on except the 8-tile headline"""
+    """csrc/brief_layout.h: brief_use_lean(train): 3 tiles and every tile count from 5 to 32 except the 8-tile headline"""
     nt = (F + 31) // 32
-    return (nt >= 5 and nt != 8) or nt == 3
+    return ((nt >= 5 and nt != 8) or nt == 3) and nt <= 32
 
 
 def fused_kernel_name(precision, F):
+    if precision == "fp32" and F > 1024:
+        nt = (F + 31) // 32
+        P = (nt + 31) // 32
+        return "k_wide<%d,true> (%d feature tiles in %d passes, K-slabs staged from the stash planes)" % ((nt + 4 * P - 1) // (4 * P), nt, P)
     if precision == "fp32" and train_on_lean(F):
         nt = (F + 31) // 32
         return "k_lean<1,%d,0,true,%d> (%d feature tiles, run-time width)" % ((nt + 3) // 4, nt % 4, nt)
@@ -87,15 +91,18 @@ def cpu_model():
 
 
 def _thread_counts():
-    nc = os.cpu_count() or 1
-    cand = sorted({t for t in (8, 16, 32, 64, 128, nc // 2, nc) if 1 <= t <= nc})
-    return cand or [1]
+    """the sweep's thread counts: oracle.thread_candidates() — the same affinity / cgroup-quota / pool-share rule the tests' oracle uses"""
+    from oracle import oracle as O
+    return O.thread_candidates()
 
 
-def _oracle_rate(O, d, p, x, y, threads, max_steps, budget):
-    """voxels/s of the oracle's train step (fwd + loss + bwd + Adamax) on this batch with `threads` OpenMP threads"""
+def _oracle_rate(O, d, p, x, y, threads, max_steps, budget, warm=0):
+    """voxels/s of the oracle's train step (fwd + loss + bwd + Adamax) on this batch with `threads` OpenMP threads (after `warm`
+    untimed samples' worth of the same step: page faults of the activation buffers, thread start)"""
     O.lib().oracle_set_num_threads(int(threads))
     pp, s1, s2 = p.copy(), np.zeros_like(p), np.zeros_like(p)
+    if warm:
+        O.loss_grad(d, pp, x[:warm], y[:warm])
     t0, steps = time.perf_counter(), 0
     while True:
         _, g, _, _ = O.loss_grad(d, pp, x, y)
@@ -109,9 +116,9 @@ def _oracle_rate(O, d, p, x, y, threads, max_steps, budget):
 def cpu_baseline():
     """The CPU beside the GPU number, on this host, same step (4x256 SIREN, fwd + loss + bwd + Adamax): the
     oracle (a C port of the reference algorithm, OpenMP over samples) and a CPU-PyTorch autograd restatement of the reference's
-    module, each at the BEST thread count of a sweep (oversubscribed hosts run slower with every core: round 3's 128-thread figure was
-    below the survey's 8-thread probe) and at 1 thread.  Bounded: sweeps on a 20 000-sample batch, the reported figure on the full
-    100 000-sample step.  `value` is the faster of the two."""
+    module.  EVERY figure — the thread sweep, the value, the one-thread rate — is timed on the REAL step, 100 000 samples, after a
+    warm-up: round 4 swept on 20 000-sample steps, whose 100 MB of activations sit in the host's L3 while the real step's 512 MB do
+    not — its sweep read 2.6x the rate its own `value` did.  `value` is the best sweep entry of the faster implementation."""
     from oracle import oracle as O
     d = O.make_desc(3, 1, LAYERS, FEATURES, W0)
     rng = np.random.default_rng(0)
@@ -120,24 +127,23 @@ def cpu_baseline():
     n = SAMPLE
     x = rng.uniform(-1, 1, size=(n, 3)).astype(np.float32)
     y = rng.uniform(0, 100, size=(n, 1)).astype(np.float32)
-    ns = 20000
     ncpu = os.cpu_count() or 1
     threads0 = O.lib().oracle_num_threads()
     sweep = {}
     for t in _thread_counts():
-        sweep[t] = _oracle_rate(O, d, p, x[:ns], y[:ns], t, 1, 0.0)[0]
+        sweep[t] = _oracle_rate(O, d, p, x, y, t, 2, 3.0, warm=20000)[0]
     best_t = max(sweep, key=sweep.get)
-    rate, steps = _oracle_rate(O, d, p, x, y, best_t, 4, 8.0)
-    one = _oracle_rate(O, d, p, x[:2000], y[:2000], 1, 1, 0.0)[0]
+    rate = sweep[best_t]
+    one = _oracle_rate(O, d, p, x, y, 1, 1, 0.0, warm=2000)[0]
     O.lib().oracle_set_num_threads(int(threads0))
+    sample = ("thread sweep %s, each entry 1-2 steps of %d samples after a 20000-sample warm-up; value = its best entry; one_thread: one %d-sample step; "
+              "oracle/siren_oracle.c (OpenMP over samples)" % (sorted(sweep), n, n))
     oracle_out = {"value": rate, "unit": "voxels/s", "threads": best_t, "one_thread": one,
-                  "thread_sweep": {str(k): v for k, v in sorted(sweep.items())},
-                  "sample": "%d step(s) of %d samples at the best thread count of the sweep (sweep: one %d-sample step per count; 1 thread: 2000 samples), "
-                            "oracle/siren_oracle.c (OpenMP over samples)" % (steps, n, ns)}
-    out = {"value": rate, "unit": "voxels/s", "cores": best_t, "kind": "port", "host_cpus": ncpu, "cpu_model": cpu_model(),
-           "sample": oracle_out["sample"], "one_thread": one, "oracle": oracle_out}
+                  "thread_sweep": {str(k): v for k, v in sorted(sweep.items())}, "sample": sample}
+    out = {"value": rate, "unit": "voxels/s", "cores": best_t, "kind": "port", "host_cpus": ncpu, "cpu_share": O.cpu_share(), "cpu_model": cpu_model(),
+           "sample": sample, "one_thread": one, "oracle": oracle_out}
     try:
-        tc = torch_cpu_baseline(x, y, p, ns)
+        tc = torch_cpu_baseline(x, y, p)
         out["torch_cpu"] = tc
         if tc["value"] > out["value"]:
             out.update({"value": tc["value"], "cores": tc["threads"], "sample": tc["sample"], "one_thread": tc["one_thread"]})
@@ -146,10 +152,10 @@ def cpu_baseline():
     return out
 
 
-def torch_cpu_baseline(x, y, p, ns=20000):
+def torch_cpu_baseline(x, y, p):
     """The same step as the reference runs it (nn.Linear + sin, F.mse_loss, autograd, torch.optim.Adamax:
-    utils/Networks.py:246-271, main.py:385-400), restated here and timed with CPU PyTorch on this host: a thread sweep on
-    `ns` samples, the best count on the full batch, and one thread."""
+    utils/Networks.py:246-271, main.py:385-400), restated here and timed with CPU PyTorch on this host: a thread sweep and one
+    thread, every entry on the full 100 000-sample step after a warm-up step."""
     import torch.nn as nn
 
     class Sine(nn.Module):
@@ -194,15 +200,14 @@ def torch_cpu_baseline(x, y, p, ns=20000):
 
     threads0 = torch.get_num_threads()
     xt, yt = torch.from_numpy(x), torch.from_numpy(y)
-    sweep = {t: rate(xt[:ns], yt[:ns], t, 1, 0.0)[0] for t in _thread_counts()}
+    sweep = {t: rate(xt, yt, t, 2, 3.0)[0] for t in _thread_counts()}
     best_t = max(sweep, key=sweep.get)
-    value, steps = rate(xt, yt, best_t, 4, 8.0)
-    one = rate(xt[:4000], yt[:4000], 1, 1, 0.0)[0]
+    one = rate(xt, yt, 1, 1, 0.0)[0]
     torch.set_num_threads(threads0)
-    return {"value": value, "unit": "voxels/s", "threads": best_t, "one_thread": one,
+    return {"value": sweep[best_t], "unit": "voxels/s", "threads": best_t, "one_thread": one,
             "thread_sweep": {str(k): v for k, v in sorted(sweep.items())},
-            "sample": "%d step(s) of %d samples after 1 warm-up at the best thread count of the sweep (sweep: one %d-sample step per count; 1 thread: "
-                      "4000 samples), torch %s CPU autograd" % (steps, x.shape[0], ns, torch.__version__)}
+            "sample": "thread sweep %s, each entry 1-2 steps of %d samples after one warm-up step; value = its best entry; one_thread: one such step after a "
+                      "warm-up; torch %s CPU autograd" % (sorted(sweep), x.shape[0], torch.__version__)}
 
 
 def divide_bench(args, dist, rank, world, dev, red_dev):
@@ -340,8 +345,49 @@ def timed_config(name, L, F, dims, sampler, n, precision, steps, tgt=None, seed=
     return {**dec, "workload": name, "layers": L, "features": F, "volume": list(dims), "samples_per_step": nb, "dtype": DTYPES[precision],
             "steps": steps, "ms_per_step": el * 1e3 / steps, "voxels_per_s": nb * steps / el,
             "step_tflops": train_f * nb / (el / steps) / 1e12, "step_frac": train_f * nb / (el / steps) / 1e12 / peak,
-            "kernel": "k_small" if small else {"fp32": "k_lean" if train_on_lean(F) else "k_fused", "bf16x3": "k_fused_x3<true>", "bf16": "k16 (body + tail launches)"}[precision],
+            "kernel": "k_small" if small else {"fp32": "k_wide" if F > 1024 else ("k_lean" if train_on_lean(F) else "k_fused"), "bf16x3": "k_fused_x3<true>", "bf16": "k16 (body + tail launches)"}[precision],
             "kernel_ms": kms, "kernel_tflops": kflop / (kms * 1e-3) / 1e12, "kernel_frac": kflop / (kms * 1e-3) / 1e12 / peak, "peak_tflops": peak}
+
+
+def device_identity(dev):
+    """what proves N ranks ran on N devices: the device's UUID (hipDeviceProp.uuid through torch), name, index and CU count"""
+    pr = torch.cuda.get_device_properties(dev)
+    uuid = getattr(pr, "uuid", None)
+    return {"index": int(dev.index if dev.index is not None else torch.cuda.current_device()), "uuid": str(uuid) if uuid is not None else None,
+            "name": pr.name, "compute_units": int(pr.multi_processor_count), "visible_devices": torch.cuda.device_count(),
+            "env": {k: os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES") if os.environ.get(k) is not None}}
+
+
+def gather_ranks(dist, rank, world, dev, backend):
+    """per-rank identity, gathered on every rank: rank, local rank, the process group's world size and backend, the device"""
+    me = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "world_size": world, "backend": backend, "pid": os.getpid(), "device": device_identity(dev)}
+    if dist is None or world == 1:
+        return [me]
+    allr = [None] * world
+    dist.all_gather_object(allr, me)
+    return allr
+
+
+def summarize(out):
+    """flat scalars the driver's parser keeps: one entry per secondary number of this line"""
+    sm = {}
+    for k, c in (out.get("configs") or {}).items():
+        sm[k + ".ms_per_step"] = round(c["ms_per_step"], 5)
+        sm[k + ".step_frac"] = round(c["step_frac"], 4)
+        sm[k + ".kernel_frac"] = round(c["kernel_frac"], 4)
+    for k in ("encode", "decode"):
+        if k in out:
+            sm[k + ".wall_seconds"] = round(out[k]["wall_seconds"], 4)
+            sm[k + ".voxels_per_s"] = round(out[k]["voxels_per_s"], 1)
+    if "decode_kernel" in out:
+        sm["decode_kernel.seconds"] = round(out["decode_kernel"]["seconds"], 5)
+        sm["decode_kernel.tflops"] = round(out["decode_kernel"]["tflops"], 2)
+    for pt in out.get("psnr_at_bitrate_sweep") or []:
+        sm["psnr_clean_db@%dsteps.F%d" % (pt["steps"], pt["features"])] = round(pt["psnr_clean_db"], 3)
+    if "psnr_at_bitrate_20000" in out:
+        q = out["psnr_at_bitrate_20000"]
+        sm["psnr_db@20000"], sm["psnr_clean_db@20000"], sm["ssim@20000"] = round(q["psnr_db"], 3), round(q["psnr_clean_db"], 3), round(q.get("ssim", float("nan")), 5)
+    return sm
 
 
 def psnr_u16(a, b):
@@ -486,6 +532,11 @@ def main():
         LAYERS, FEATURES = 9, 512
 
     if world > 1 or args.divide:
+        ranks = gather_ranks(dist, rank, world, dev, backend)
+        uuids = [r["device"]["uuid"] for r in ranks]
+        if backend == "nccl" and world > 1 and None not in uuids and len(set(uuids)) != world:
+            sys.stderr.write("bench.py: %d ranks on %d distinct devices (%s): one rank per GPU is the contract\n" % (world, len(set(uuids)), uuids))
+            sys.exit(2)
         elapsed, fused_ms, perf, pcount = divide_bench(args, dist, rank, world, dev, red_dev)
         if rank == 0:
             train_f, fused_f, _ = flops_per_sample(LAYERS, FEATURES)
@@ -501,11 +552,12 @@ def main():
                                        % (world, BLOCK[0], world, LAYERS - 1, FEATURES, LAYERS, FEATURES),
                            "volume": [world * BLOCK[0], BLOCK[1], BLOCK[2]], "layers": LAYERS, "features": FEATURES, "sample_size": SAMPLE,
                            "params": pcount, "bits_per_voxel": 32.0 * pcount / float(np.prod(BLOCK))},
+                "distinct_devices": len(set(uuids)) if None not in uuids else None, "backend": backend,
                 "roofline": {"bound": "mfma", "kernel": fused_kernel_name(args.precision, FEATURES)
                              + " (forward+loss+dgrad), rank 0", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                              "traffic": None, "traffic_source": None, "kernel_ms": fused_ms, "flop_per_launch": fused_f * SAMPLE,
                              "step_tflops": train_f * SAMPLE / (ms_step * 1e-3) / 1e12, "step_frac": train_f * SAMPLE / (ms_step * 1e-3) / 1e12 / peak},
-                "preroll_steps": args.preroll,
+                "preroll_steps": args.preroll, "ranks": ranks,
                 "psnr_at_bitrate": {"steps": args.preroll + args.warmup + args.steps, "bits_per_voxel": 32.0 * pcount / float(np.prod(BLOCK)),
                                     "psnr_db": perf.get("psnr"), "ssim": perf.get("ssim"),
                                     "note": "merged volume, z-sharded decode, [SSE, SSIM-sum, slices, voxels] all-reduced over the ranks"},
@@ -611,6 +663,9 @@ def main():
             cfgs["default_yaml_512cube_4x527"] = timed_config("SingleTask default.yaml (ratio 80) on the 512^3 uint16 volume: the budget solves to SIREN 4x527 "
                                                               "(layers=5, features=527 = 17 feature tiles), randompoint sample_size=100000; k_lean + k_wgrad<0,6>",
                                                               5, 527, BLOCK, "randompoint", SAMPLE, "fp32", 40, tgt=tgt)
+            cfgs["default_yaml_1024cube_4x1495"] = timed_config("the net opt/SingleTask/default.yaml (ratio 80) solves to on a 1024^3 uint16 volume: SIREN 4x1495 (layers=5, "
+                                                               "features=1495 = 47 feature tiles), randompoint sample_size=100000, sampled on this bench's 512^3 volume; "
+                                                               "k_wide<6,true> + k_wgrad<0,8>", 5, 1495, BLOCK, "randompoint", SAMPLE, "fp32", 10, tgt=tgt)
             cfgs["c3_512cube_8x512_bf16"] = timed_config("SingleTask 512^3 synthetic volume, SIREN 8x512 (layers=9, features=512), bf16 MFMA with f32 master weights, "
                                                          "randompoint sample_size=100000", 9, 512, BLOCK, "randompoint", SAMPLE, "bf16", 60, tgt=tgt)
             cfgs["c2_512cube_4x256_bf16x3"] = timed_config("the headline workload (SingleTask 512^3, SIREN 4x256, randompoint sample_size=100000) under precision="
@@ -653,7 +708,7 @@ def main():
         # read from the committed counter passes of this same command (tools/profile_round.sh: separate --pmc FETCH_SIZE /
         # WRITE_SIZE passes, 2*FETCH_SIZE + WRITE_SIZE per launch, the guide's gfx950 correction) and labelled as such
         traffic, traffic_src = None, None
-        for tag in ("r04", "r03", "r02", "r01"):
+        for tag in ("r05", "r04", "r03", "r02", "r01"):
             try:
                 with open(os.path.join(ROOT, "profiles", tag + "_traffic.json")) as f:
                     traffic = float(json.load(f)["k_fused"]["hbm_bytes"])
@@ -688,10 +743,18 @@ def main():
             "loss": float(loss.item()), "preroll_steps": pre,
             "psnr_at_bitrate": {"steps": steps_done, "bits_per_voxel": 32.0 * net.param_count / float(np.prod(BLOCK)), "psnr_db": psnr, **q2k_out},
         }
-        out.update(extra)
+        out["ranks"] = gather_ranks(dist, rank, world, dev, backend)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        # the secondary numbers as flat scalars, EARLY in the line (`summary`) and once more inside `roofline` (which the driver's record keeps):
+        # per-config ms_per_step / step_frac / kernel_frac, encode / decode wall clocks, the PSNR points
+        sm = summarize({**out, **extra})
+        out["summary"] = sm
+        out["roofline"].update({"cfg." + k: v for k, v in sm.items() if k.endswith((".step_frac", ".kernel_frac"))})
+        head = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "summary",
+                "roofline", "cpu_baseline")
+        out = {**{k: out[k] for k in head if k in out}, **{k: v for k, v in out.items() if k not in head}, **extra}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -40,3 +40,13 @@ def golden():
             cache[name] = dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
         return cache[name]
     return load
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """the parity bands this session applied (tests/_bands.py) -> gpurun_out/r05/parity_bands.json (merged back from the GPU box)"""
+    try:
+        from tests import _bands
+    except Exception:
+        return
+    if _bands.CASES:
+        _bands.dump(os.path.join(ROOT, "gpurun_out", "r05", "parity_bands.json"))

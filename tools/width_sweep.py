@@ -1,4 +1,4 @@
-"""step / k_fused time and fraction of the fp32 MFMA peak over net widths: python tools/width_sweep.py L F1,F2,... [n] [steps]
+"""step / k_fused time and fraction of the fp32 MFMA peak over net widths: python tools/width_sweep.py L F1,F2,... [n] [steps] [pre-roll steps]
 (algorithmic FLOPs of SURVEY 8d: train 2(3M - cin F) per sample; k_fused: forward 2M + dgrad + skinny gradients)"""
 import ctypes as C
 import sys
@@ -12,13 +12,14 @@ L = int(sys.argv[1])
 Fs = [int(v) for v in sys.argv[2].split(',')]
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 100000
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 100
+preroll = int(sys.argv[5]) if len(sys.argv) > 5 else 300
 PEAK = 157.3e12
 tv = torch.rand(256 ** 3, 1, device='cuda') * 100
 for F in Fs:
     torch.manual_seed(0)
     m = SIREN(features=F, layers=L, w0=20).to('cuda')
     fit = Fitter(m, tv, (256, 256, 256), sampler='randompoint', sample_size=n)
-    fit.run(300)
+    fit.run(preroll)
     torch.cuda.synchronize()
     _lib.check(_lib.lib().brief_profile_enable(1))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
