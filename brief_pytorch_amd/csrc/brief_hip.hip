@@ -334,7 +334,7 @@ static Ws16 ws16_layout(const brief_siren_desc &d, int64_t n)
     return w;
 }
 
-struct WsLayout { int64_t z, dd, rec, slabs, table, total; };
+struct WsLayout { int64_t z, dd, rec, slabs, table, img, total; };
 // per-wave records of the fused kernel (k_wide: one workgroup per CU; everything else: up to kRecWgsPerCu)
 static int64_t rec_region_floats(const brief_siren_desc &d)
 {
@@ -343,7 +343,7 @@ static int64_t rec_region_floats(const brief_siren_desc &d)
 static WsLayout ws_layout(const brief_siren_desc &d, int64_t n)
 {
     if (d.precision == BRIEF_PREC_BF16) {
-        WsLayout w; w.z = w.dd = w.rec = w.slabs = w.table = 0; w.total = ws16_layout(d, n).total;
+        WsLayout w; w.z = w.dd = w.rec = w.slabs = w.table = w.img = 0; w.total = ws16_layout(d, n).total;
         return w;
     }
     const int nt = brief_nt(d);
@@ -356,7 +356,9 @@ static WsLayout ws_layout(const brief_siren_desc &d, int64_t n)
     w.slabs = w.rec + rec_region_floats(d);
     w.table = w.slabs + hidden * (int64_t)(small ? small_grid(d, n) : wgrad_splits(d, n)) * (FP * FP + FP);
     w.table = (w.table + 3) / 4 * 4;
-    w.total = w.table + (small ? kGroupTableFloats : 0);
+    w.img = w.table + (small ? kGroupTableFloats : 0);
+    w.img = (w.img + 63) / 64 * 64;                                  // k_wide: two image-ordered ping-pong planes per workgroup (256-byte aligned)
+    w.total = w.img + (brief_use_wide(d) ? (int64_t)kCUs * 2 * FP * 32 : 0);
     return w;
 }
 
@@ -732,7 +734,7 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
     fill_grid(fa.grid, grid);
     fa.loss_kind = loss_kind; fa.thr = thr; fa.beta = beta; fa.inv_count = inv_count;
     fa.Z = ws + wl.z; fa.D = ws + wl.dd; fa.npad = brief_npad_d(*d, batch->n);
-    fa.rec = ws + wl.rec; fa.slabs = ws + wl.slabs; fa.yhat_out = yhat_out;
+    fa.rec = ws + wl.rec; fa.slabs = brief_use_wide(*d) ? ws + wl.img : ws + wl.slabs; fa.yhat_out = yhat_out;      // (k_small: its slabs; k_wide: its image planes)
     fa.stagger_cus = kCUs; fa.stagger = g_stagger; fa.diag = g_diag;
     fa.pers_wgs = fp.pers_wgs; fa.pers_tiles = fp.pers_tiles;
     ReduceArgs ra;
