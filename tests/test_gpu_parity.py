@@ -473,8 +473,8 @@ def test_sample_indices_and_sse():
 
 def test_errors_are_loud():
     L = _lib.lib()
-    d = _lib.SirenDesc(3, 1, 5, 1100, 20.0, 30.0, 0, 0)
-    assert L.brief_packed_count(C.byref(d)) == -1
+    d = _lib.SirenDesc(3, 1, 5, 5000, 20.0, 30.0, 0, 0)            # (widths up to 4096 features run: tests/test_gpu_wider.py)
+    assert L.brief_packed_count(C.byref(d)) == -1 and b"4096" in L.brief_last_error()
     m, _, _ = make_net(3, 16, 20.0)
     with pytest.raises(_lib.BriefError):
         m.train_step(10, torch.zeros(10, 1, device=DEV), coords=None, grid=((4, 4), -1.0, 1.0))   # ndim != cin
