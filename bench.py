@@ -663,9 +663,9 @@ def main():
             cfgs["default_yaml_512cube_4x527"] = timed_config("SingleTask default.yaml (ratio 80) on the 512^3 uint16 volume: the budget solves to SIREN 4x527 "
                                                               "(layers=5, features=527 = 17 feature tiles), randompoint sample_size=100000; k_lean + k_wgrad<0,6>",
                                                               5, 527, BLOCK, "randompoint", SAMPLE, "fp32", 40, tgt=tgt)
-            cfgs["default_yaml_1024cube_4x1495"] = timed_config("the net opt/SingleTask/default.yaml (ratio 80) solves to on a 1024^3 uint16 volume: SIREN 4x1495 (layers=5, "
-                                                               "features=1495 = 47 feature tiles), randompoint sample_size=100000, sampled on this bench's 512^3 volume; "
-                                                               "k_wide<6,true> + k_wgrad<0,8>", 5, 1495, BLOCK, "randompoint", SAMPLE, "fp32", 10, tgt=tgt)
+            cfgs["default_yaml_1024cube_4x1494"] = timed_config("the net opt/SingleTask/default.yaml (ratio 80) solves to on a 1024^3 uint16 volume: SIREN 4x1494 (layers=5, "
+                                                               "features=1494 = 47 feature tiles), randompoint sample_size=100000, sampled on this bench's 512^3 volume; "
+                                                               "k_wide<6,true> + k_wgrad<0,8>", 5, 1494, BLOCK, "randompoint", SAMPLE, "fp32", 10, tgt=tgt)
             cfgs["c3_512cube_8x512_bf16"] = timed_config("SingleTask 512^3 synthetic volume, SIREN 8x512 (layers=9, features=512), bf16 MFMA with f32 master weights, "
                                                          "randompoint sample_size=100000", 9, 512, BLOCK, "randompoint", SAMPLE, "bf16", 60, tgt=tgt)
             cfgs["c2_512cube_4x256_bf16x3"] = timed_config("the headline workload (SingleTask 512^3, SIREN 4x256, randompoint sample_size=100000) under precision="

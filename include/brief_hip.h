@@ -35,7 +35,7 @@ typedef struct {
     int32_t cout;        /* 1 .. 4 */
     int32_t layers;      /* >= 2 */
     int32_t features;    /* 1 .. 4096 for BRIEF_PREC_F32 (padded internally to whole 32-feature tiles; SIREN.calc_features, utils/Networks.py:299-314,
-                          * has no width limit: the shipped default.yaml solves to 527 on a 512^3 uint16 volume and to 1495 on a 1024^3 one), 1 .. 512 for BRIEF_PREC_BF16,
+                          * has no width limit: the shipped default.yaml solves to 527 on a 512^3 uint16 volume and to 1494 on a 1024^3 one), 1 .. 512 for BRIEF_PREC_BF16,
                           * 1 .. 256 for BRIEF_PREC_BF16X3 */
     float w0_first;
     float w0_hidden;

@@ -88,13 +88,13 @@ def test_capi_exports_and_sizes():
     assert L.brief_packed_count(C.byref(w527)) == 544 * 4 + 3 * (2 * 544 * 544 + 544) + 4 * 544 + 4
     assert L.brief_packed_count(C.byref(_lib.SirenDesc(3, 1, 5, 1024, 20.0, 30.0, 0, 0))) == 1024 * 4 + 3 * (2 * 1024 * 1024 + 1024) + 4 * 1024 + 4
     assert L.brief_train_workspace_bytes(C.byref(w527), 100000) > 6 * 544 * 100000 * 4
-    # above 1024 features (k_wide): still exact tiles; the default.yaml budget of a 1024^3 uint16 volume solves to 1495 = 47 tiles.  Inference
+    # above 1024 features (k_wide): still exact tiles; the default.yaml budget of a 1024^3 uint16 volume solves to 1494 = 47 tiles.  Inference
     # needs a scratch there (two ping-pong planes per workgroup), training one more phase plane than narrower nets
-    w1495 = _lib.SirenDesc(3, 1, 5, 1495, 20.0, 30.0, 0, 0)
-    assert L.brief_packed_count(C.byref(w1495)) == 1504 * 4 + 3 * (2 * 1504 * 1504 + 1504) + 4 * 1504 + 4
-    assert L.brief_forward_workspace_bytes(C.byref(w1495), 32 * 7) == 7 * 2 * 1504 * 32 * 4
+    w1494 = _lib.SirenDesc(3, 1, 5, 1494, 20.0, 30.0, 0, 0)
+    assert L.brief_packed_count(C.byref(w1494)) == 1504 * 4 + 3 * (2 * 1504 * 1504 + 1504) + 4 * 1504 + 4
+    assert L.brief_forward_workspace_bytes(C.byref(w1494), 32 * 7) == 7 * 2 * 1504 * 32 * 4
     assert L.brief_forward_workspace_bytes(C.byref(w527), 100000) == 0
-    assert L.brief_train_workspace_bytes(C.byref(w1495), 100000) > 7 * 1504 * 100000 * 4
+    assert L.brief_train_workspace_bytes(C.byref(w1494), 100000) > 7 * 1504 * 100000 * 4
     bad = _lib.SirenDesc(3, 1, 5, 4097, 20.0, 30.0, 0, 0)
     assert L.brief_param_count(C.byref(bad)) == -1 and b"features" in L.brief_last_error()
     assert L.brief_param_count(C.byref(_lib.SirenDesc(3, 1, 5, 513, 20.0, 30.0, 0, 1))) == -1 and b"BF16" in L.brief_last_error()

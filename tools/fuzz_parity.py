@@ -23,7 +23,7 @@ plain = [0.0, 0.0]      # worst forward / gradient distance against the PLAIN ba
 over = [0, 0, 0]        # cases outside the plain forward band | outside the plain gradient band | with a widened band
 widths = list(range(1, 65)) + [65, 95, 96, 97, 127, 128, 129, 160, 191, 192, 200, 223, 224, 255, 256, 257, 288, 289, 300, 320, 383, 384, 385, 416, 450, 480, 511, 512,
           513, 527, 544, 545, 576, 600, 640, 641, 700, 768, 769, 800, 832, 896, 897, 960, 1000, 1023, 1024,      # round 4: every tile count 9 .. 32 (k_lean)
-          1025, 1100, 1280, 1495, 2048]      # round 5: k_wide (passes of 5 .. 8 tile slots)
+          1025, 1100, 1280, 1494, 2048]      # round 5: k_wide (passes of 5 .. 8 tile slots)
 bad = 0
 for case in range(cases):
     L = int(rng.integers(2, 12))
