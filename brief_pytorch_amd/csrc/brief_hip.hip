@@ -99,6 +99,9 @@ struct DevState {
     bool pool_init, prof_init;
     hipStream_t pool[kPoolStreams];
     hipEvent_t pool_ev[kPoolStreams + 1];
+    bool aux_init;                      // the side stream of the bf16 overlap plan (train_step_impl) and its fork / join events
+    hipStream_t aux;
+    hipEvent_t aux_fork, aux_join;
     hipEvent_t *prof_ev;                // [2 * kProfSlots]
     int nattr;
     const void *attr_fn[256];           // kernels whose hipFuncAttributeMaxDynamicSharedMemorySize was set on this device
@@ -291,8 +294,58 @@ static int grid16(int64_t n)
     const int64_t tiles = (n + 127) / 128;
     return (int)(tiles < kCUs ? (tiles > 0 ? tiles : 1) : kCUs);
 }
+// How a batch is cut into launches of k16: a body of whole rounds of 128-sample tiles (one per CU), then what is left
+// as quarter (NS = 1) or half (NS = 2) tiles when that spreads it over more CUs.  Multi-channel nets (CO = 4 kernels)
+// only exist with NS = 4.
+struct Split16 { int64_t n_body; int g_body, ns_tail, g_tail; };
+static Split16 split16(const brief_siren_desc &d, int64_t n)
+{
+    Split16 s;
+    const int64_t tiles = (n + 127) / 128;
+    const int64_t full = tiles / kCUs * kCUs, rem = tiles - full;
+    s.n_body = n; s.g_body = (int)(tiles < kCUs ? tiles : kCUs); s.ns_tail = 0; s.g_tail = 0;
+    if (d.cout != 1 || rem == 0) return s;
+    int ns = rem * 4 <= kCUs ? 1 : (rem * 2 <= kCUs ? 2 : 0);
+    if (!ns) return s;
+    s.n_body = full * 128;
+    s.g_body = full > 0 ? kCUs : 0;
+    s.ns_tail = ns;
+    s.g_tail = (int)((npad16(n) - s.n_body) / (32 * ns));          // tiles up to the padded size (see k16)
+    return s;
+}
+// The overlap plan of the 512-wide bf16 step (BASELINE config 3).  A 100 000-sample batch is 768 full 128-sample tiles + a remainder that runs as a
+// second, quarter-tile launch of k16: 109 us for 1.7 % of the samples (a tile of any size streams the net's 7 MB of bf16 fragments through its
+// CU), and the skinny first-layer / head job behind the weight-gradient GEMM is another 48 us of latency-bound launch — 157 us in which most of
+// the chip idles.  Neither depends on k_wgrad16_big's work on the BODY's samples, so:
+//     stream:      k16 body ─┬─ k_wgrad16_big over the body's sample blocks, na splits (hidden x 4 x na workgroups <= CUs - tail's share) ─┬─ k_reduce ...
+//     side stream:           └─ k16 tail ─ k_wgrad16_big over the tail's blocks (one more split) ─ skinny job ───────────────────────────────┘
+// The side work runs on the CUs the first launch leaves free (its workgroups own a CU each: 512 threads x 256 registers), in its shadow.
+// Slabs are summed by k_reduce in slab order as before: results depend on the plan (a function of the job alone), not on timing.
+struct Split16Plan { bool on; int na; int64_t kb_body; };      // na: K splits of the body part (the tail's blocks are split na)
+static Split16Plan split16_plan(const brief_siren_desc &d, int64_t n)
+{
+    Split16Plan p;
+    p.on = false; p.na = 0; p.kb_body = 0;
+    const int hidden = d.layers - 2;
+    if (d.precision != BRIEF_PREC_BF16 || brief_nt(d) != 16 || hidden < 1) return p;
+    const Split16 sp = split16(d, n);
+    if (sp.g_tail <= 0 || sp.g_body <= 0) return p;
+    const int free_cus = (sp.g_tail + 1) / 2;                       // the tail's workgroups in at most two rounds
+    int na = (kCUs - free_cus) / (hidden * 4);
+    if (na > 15) na = 15;
+    if (na < 1 || sp.n_body / 64 < na) return p;
+    p.on = true; p.na = na; p.kb_body = sp.n_body / 64;
+    return p;
+}
+
+static int wgrad16_overlap_splits(const brief_siren_desc &d, int64_t n)
+{
+    const Split16Plan p = split16_plan(d, n);
+    return p.on ? p.na + 1 : 0;
+}
 static int wgrad16_splits(const brief_siren_desc &d, int64_t n)
 {
+    if (const int ov = wgrad16_overlap_splits(d, n)) return ov;      // the overlap plan: its body splits + one for the tail
     const int nt = brief_nt(d);
     const int hidden = d.layers - 2 > 0 ? d.layers - 2 : 0;
     const int64_t nblk = npad16(n) / 64;          // K is split in 64-sample blocks; every split needs one
@@ -528,25 +581,6 @@ static int launch_k16(const FusedArgs &fa, int grid, hipStream_t st, int ns)
     return 0;
 }
 
-// How a batch is cut into launches of k16: a body of whole rounds of 128-sample tiles (one per CU), then what is left
-// as quarter (NS = 1) or half (NS = 2) tiles when that spreads it over more CUs.  Multi-channel nets (CO = 4 kernels)
-// only exist with NS = 4.
-struct Split16 { int64_t n_body; int g_body, ns_tail, g_tail; };
-static Split16 split16(const brief_siren_desc &d, int64_t n)
-{
-    Split16 s;
-    const int64_t tiles = (n + 127) / 128;
-    const int64_t full = tiles / kCUs * kCUs, rem = tiles - full;
-    s.n_body = n; s.g_body = (int)(tiles < kCUs ? tiles : kCUs); s.ns_tail = 0; s.g_tail = 0;
-    if (d.cout != 1 || rem == 0) return s;
-    int ns = rem * 4 <= kCUs ? 1 : (rem * 2 <= kCUs ? 2 : 0);
-    if (!ns) return s;
-    s.n_body = full * 128;
-    s.g_body = full > 0 ? kCUs : 0;
-    s.ns_tail = ns;
-    s.g_tail = (int)((npad16(n) - s.n_body) / (32 * ns));          // tiles up to the padded size (see k16)
-    return s;
-}
 template <bool TRAIN>
 static int launch_k16_split(FusedArgs &fa, hipStream_t st)
 {
@@ -673,27 +707,64 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
         fa.S16[0] = ws + w16.h; fa.S16[1] = nullptr; fa.S16[2] = ws + w16.dd; fa.S16[3] = ws + w16.x; fa.S16[4] = ws + w16.g;
         const bool prof16 = prof_live();
         hipEvent_t *pev16 = prof16 ? dev_state()->prof_ev : nullptr;
+        const Split16Plan ov = split16_plan(*d, batch->n);      // overlap plan (512-wide nets with a tail launch): see split16_plan
+        hipStream_t side = st;
+        if (ov.on) {
+            DevState *ds = dev_state();
+            if (!ds) return fail(BRIEF_ERR_INVALID, "out of host memory");
+            if (!ds->aux_init) {
+                int least = 0, greatest = 0;
+                HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+                HIP_TRY(hipStreamCreateWithPriority(&ds->aux, hipStreamNonBlocking, least));      // the main launch's workgroups go first
+                HIP_TRY(hipEventCreateWithFlags(&ds->aux_fork, hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&ds->aux_join, hipEventDisableTiming));
+                ds->aux_init = true;
+            }
+            side = ds->aux;
+        }
         if (prof16) HIP_TRY(hipEventRecord(pev16[2 * g_prof_n], st));
-        if (int rc = launch_k16_split<true>(fa, st)) return rc;
-        if (prof16) { HIP_TRY(hipEventRecord(pev16[2 * g_prof_n + 1], st)); ++g_prof_n; }
+        if (!ov.on) {
+            if (int rc = launch_k16_split<true>(fa, st)) return rc;
+        } else {
+            fa.n_begin = 0; fa.n_end = sp16.n_body; fa.rec_base = 0;
+            if (int rc = launch_k16<true>(fa, sp16.g_body, st, 4)) return rc;
+            HIP_TRY(hipEventRecord(dev_state()->aux_fork, st));
+            HIP_TRY(hipStreamWaitEvent(side, dev_state()->aux_fork, 0));
+            fa.n_begin = sp16.n_body; fa.n_end = np; fa.rec_base = sp16.g_body;
+            if (int rc = launch_k16<true>(fa, sp16.g_tail, side, sp16.ns_tail)) return rc;
+        }
+        if (prof16) { HIP_TRY(hipEventRecord(pev16[2 * g_prof_n + 1], side)); ++g_prof_n; }      // (overlap plan: from the body's start to the tail's end)
         Wgrad16Args wa;
         memset(&wa, 0, sizeof(wa));
         const int nsp_s = wgrad16_skinny_splits(*d, batch->n);
         wa.d = *d; wa.npad = np; wa.nsplit = nsp; wa.nsplit_s = nsp_s; wa.bias_jobs = 0; wa.slabs = ws + w16.slabs;   // (bias_jobs: k_wgrad16_big computes db_l itself since round 2)
         wa.H = (const __bf16 *)(ws + w16.h); wa.D = (const __bf16 *)(ws + w16.dd);
         wa.X = (const __bf16 *)(ws + w16.x); wa.G = (const __bf16 *)(ws + w16.g);
+        wa.kb_lo = 0; wa.kb_hi = np / 64; wa.split_lo = 0; wa.nsplit_here = nsp;
         const int nb = nt / 4;
         if (hidden > 0 && nt == 16) {
             const int lds_big = (int)(sizeof(float) * 4 * W16B_PANEL);
             if (int rc = dev_attr_once((const void *)k_wgrad16_big, lds_big)) return rc;
-            const int groups8 = (hidden * nsp + 7) / 8 * 8;        // (layer, split) groups padded to whole XCD rounds (see the kernel)
-            hipLaunchKernelGGL(k_wgrad16_big, dim3(groups8 * 4), dim3(512), lds_big, st, wa);
+            if (ov.on) {
+                // the body's blocks in ov.na splits on the caller's stream, the tail's blocks as split number ov.na on the side stream
+                wa.kb_lo = 0; wa.kb_hi = ov.kb_body; wa.split_lo = 0; wa.nsplit_here = ov.na;
+                hipLaunchKernelGGL(k_wgrad16_big, dim3((hidden * ov.na + 7) / 8 * 8 * 4), dim3(512), lds_big, st, wa);
+                wa.kb_lo = ov.kb_body; wa.kb_hi = np / 64; wa.split_lo = ov.na; wa.nsplit_here = 1;
+                hipLaunchKernelGGL(k_wgrad16_big, dim3((hidden + 7) / 8 * 8 * 4), dim3(512), lds_big, side, wa);
+            } else {
+                const int groups8 = (hidden * nsp + 7) / 8 * 8;        // (layer, split) groups padded to whole XCD rounds (see the kernel)
+                hipLaunchKernelGGL(k_wgrad16_big, dim3(groups8 * 4), dim3(512), lds_big, st, wa);
+            }
         } else if (hidden > 0) {
             hipLaunchKernelGGL(k_wgrad16<false>, dim3(hidden * nb * nb * nsp), dim3(256), sizeof(float) * 4 * W16_PANEL, st, wa);
         }
         // hidden-layer bias gradients (B = ones), first layer, head
-        hipLaunchKernelGGL(k_wgrad16<true>, dim3((wa.bias_jobs ? hidden * nb * nsp : 0) + 2 * nb * nsp_s), dim3(256), sizeof(float) * 4 * W16_PANEL, st, wa);
+        hipLaunchKernelGGL(k_wgrad16<true>, dim3((wa.bias_jobs ? hidden * nb * nsp : 0) + 2 * nb * nsp_s), dim3(256), sizeof(float) * 4 * W16_PANEL, side, wa);
         HIP_TRY(hipGetLastError());
+        if (ov.on) {
+            HIP_TRY(hipEventRecord(dev_state()->aux_join, side));
+            HIP_TRY(hipStreamWaitEvent(st, dev_state()->aux_join, 0));
+        }
         const int64_t l0c = (int64_t)d->features * d->cin + d->features;
         const int64_t hcnt = brief_canon_head_off(*d) - l0c;
         if (hidden > 0) {
