@@ -52,7 +52,7 @@ md = """# round %s — final profile of the bench workload (4x256 SIREN, 100 000
 Commands (MI355X, ROCm 7.2; `tools/profile_round.sh`, summarised by `tools/make_profile_summary.py`):
 * `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-psnr --no-extras`
 * `rocprofv3 --kernel-trace --pmc FETCH_SIZE ...`, `--pmc WRITE_SIZE ...`, `--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE ...` (separate passes, `--steps 10 --warmup 2 --preroll 20`)
-* `python3 bench.py` (the default line, with the CPU baseline): `profiles/%s_bench_line.json`
+* `python3 bench.py --steps 20 --warmup 5` (the driver's flags; configs, sweeps, wall clocks and the CPU baseline included): `profiles/%s_bench_line.json`
 
 bench line of the kernel-trace run: %s
 
