@@ -26,5 +26,5 @@ def dump(path):
 
 
 # what the audit asserts (tests/test_zz_band_audit.py)
-MAX_WIDENED_FRACTION = {"grad": 0.15, "forward": 0.15, "trace": 0.5}
+MAX_WIDENED_FRACTION = {"grad": 0.15, "forward": 0.15}      # (loss-trace steps: no fraction — each widened step is held to 3x the oracle's own distance instead)
 MAX_BAND = {"grad": 1e-3, "forward": 2e-4, "trace": 5e-2}
