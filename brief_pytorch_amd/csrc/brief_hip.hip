@@ -243,12 +243,14 @@ static int wgrad_splits(const brief_siren_desc &d, int64_t n)
     int64_t s = kWgradBlocks / (hidden * wgrad_nq(brief_nt(d)) * wgrad_nq(brief_nt(d)));
     if (s < 1) s = 1;
     if (brief_nt(d) > 32) {
-        // above 1024 features one K split already has about as many quadrant blocks as the device has CUs (4x2048: 192): take the
-        // split count whose blocks fill whole rounds best (a slab per split is FP^2 floats, which k_reduce pays for: 2 % per split)
+        // above 1024 features one K split already has about as many quadrant blocks as the device has CUs (4x2048: 192, 4x1494: 108): take the
+        // split count (<= 8) whose blocks fill whole rounds best.  A split more costs k_reduce one more slab per layer (FP^2 floats: 9 MB at 1 494
+        // features = ~7 us at the 4 TB/s it reads) against a k_wgrad of ~12 ms: 0.001 of the launch per split in this model — 4x1494 takes 7 splits
+        // (756 workgroups = 2.95 rounds) where 2 (216 = 0.84 of a round) cost it 14 % of the launch
         const int64_t B = (int64_t)hidden * wgrad_nq(brief_nt(d)) * wgrad_nq(brief_nt(d));
         double best = 1e30;
         for (int64_t c = 1; c <= 8; ++c) {
-            const double cost = (double)((c * B + kWgradBlocks - 1) / kWgradBlocks) / (double)c + 0.02 * (double)c;
+            const double cost = (double)((c * B + kWgradBlocks - 1) / kWgradBlocks) / (double)c + 0.001 * (double)c;
             if (cost < best - 1e-9) { best = cost; s = c; }
         }
     }
