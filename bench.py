@@ -57,8 +57,8 @@ def train_on_lean(F):
 def fused_kernel_name(precision, F):
     if precision == "fp32" and F > 1024:
         nt = (F + 31) // 32
-        P = (nt + 31) // 32
-        return "k_wide<%d,true> (%d feature tiles in %d passes, K-slabs staged from the stash planes)" % ((nt + 4 * P - 1) // (4 * P), nt, P)
+        m, P = min(((mm, (nt + 4 * mm - 1) // (4 * mm)) for mm in range(8, 2, -1)), key=lambda t: 4 * t[0] * t[1] * (1.0 + 0.015 * t[1]))      # csrc/brief_wide.inc: wide_mtw
+        return "k_wide<%d,true> (%d feature tiles in %d passes, K-slabs staged from image-ordered planes)" % (m, nt, P)
     if precision == "fp32" and train_on_lean(F):
         nt = (F + 31) // 32
         return "k_lean<1,%d,0,true,%d> (%d feature tiles, run-time width)" % ((nt + 3) // 4, nt % 4, nt)

@@ -244,12 +244,12 @@ static int wgrad_splits(const brief_siren_desc &d, int64_t n)
     if (s < 1) s = 1;
     if (brief_nt(d) > 32) {
         // above 1024 features one K split already has about as many quadrant blocks as the device has CUs (4x2048: 192, 4x1494: 108): take the
-        // split count (<= 8) whose blocks fill whole rounds best.  A split more costs k_reduce one more slab per layer (FP^2 floats: 9 MB at 1 494
+        // split count (<= 16) whose blocks fill whole rounds best.  A split more costs k_reduce one more slab per layer (FP^2 floats: 9 MB at 1 494
         // features = ~7 us at the 4 TB/s it reads) against a k_wgrad of ~12 ms: 0.001 of the launch per split in this model — 4x1494 takes 7 splits
         // (756 workgroups = 2.95 rounds) where 2 (216 = 0.84 of a round) cost it 14 % of the launch
         const int64_t B = (int64_t)hidden * wgrad_nq(brief_nt(d)) * wgrad_nq(brief_nt(d));
         double best = 1e30;
-        for (int64_t c = 1; c <= 8; ++c) {
+        for (int64_t c = 1; c <= 16; ++c) {
             const double cost = (double)((c * B + kWgradBlocks - 1) / kWgradBlocks) / (double)c + 0.001 * (double)c;
             if (cost < best - 1e-9) { best = cost; s = c; }
         }
@@ -499,7 +499,7 @@ static int launch_fused(const FusedArgs &fa, int grid, hipStream_t st, hipEvent_
     }
 #endif
     if (brief_use_wide(fa.d)) {
-        // k_wide<MTW, TRAIN>: 33 .. 128 feature tiles, output tiles in ceil(nt / 32) passes of 4 waves x MTW, K-slabs staged from the planes
+        // k_wide<MTW, TRAIN>: 33 .. 128 feature tiles, output tiles in ceil(nt / 4 MTW) passes of 4 waves x MTW slots, K-slabs staged from the image planes
         const int mtw = wide_mtw(nt);
         const size_t lds = sizeof(float) * wide_lds(mtw).total;
         if (!fa.Z) return fail(BRIEF_ERR_WORKSPACE, "widths above 1024 features evaluate through a scratch: call brief_siren_forward_ws with brief_forward_workspace_bytes() bytes");
@@ -509,7 +509,7 @@ static int launch_fused(const FusedArgs &fa, int grid, hipStream_t st, hipEvent_
         launch_timed(k_wide<MTWV, TRAIN>, grid, 256, lds, st, fa, e0, e1);                               \
         break;
         switch (mtw) {
-            BRIEF_WIDE_CASE(5) BRIEF_WIDE_CASE(6) BRIEF_WIDE_CASE(7) BRIEF_WIDE_CASE(8)
+            BRIEF_WIDE_CASE(3) BRIEF_WIDE_CASE(4) BRIEF_WIDE_CASE(5) BRIEF_WIDE_CASE(6) BRIEF_WIDE_CASE(7) BRIEF_WIDE_CASE(8)
         default: return fail(BRIEF_ERR_INVALID, "unsupported width");
         }
 #undef BRIEF_WIDE_CASE
