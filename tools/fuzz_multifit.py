@@ -25,7 +25,7 @@ for gi in range(groups):
     k = int(rng.integers(1, 7)) if gi % 3 else int(rng.integers(8, 80))      # every third group: many jobs (several k_small_group launches of up to 64)
     specs = []
     for _ in range(k):
-        F = int(rng.choice([5, 22, 33, 56, 64, 96, 130, 200, 256, 340])) if k < 8 else int(rng.choice([5, 22, 22, 30, 33, 56, 64, 96]))
+        F = int(rng.choice([5, 22, 33, 56, 64, 96, 130, 200, 256, 340, 527, 1100])) if k < 8 else int(rng.choice([5, 22, 22, 30, 33, 56, 64, 96]))
         L = int(rng.integers(3, 8))
         prec = 'bf16' if (F >= 96 and rng.random() < 0.3) else 'fp32'
         dims = tuple(int(v) for v in rng.choice([8, 12, 16, 20, 24], size=3))
