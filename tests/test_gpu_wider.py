@@ -24,9 +24,10 @@ DEV = "cuda"
 
 
 # tile counts 35 (2 passes x 5 slots, wave 3 short), 47 (the default.yaml width on 1024^3: 2 x 6), 57 (2 x 8, short), 64 (2 x 8 exact),
-# 66 (3 passes x 6), 94 (3 x 8), 128 (4 x 8: the maximum); two-channel coordinates, RGB outputs, no hidden layer, output activation
+# 66 (3 passes x 6), 94 (3 x 8), 128 (4 x 8: the maximum); two-channel coordinates, RGB outputs, no hidden layer, output activation, a one-sample batch
+# (the host picks (passes, slots per wave) for the fewest empty tile slots: 35 tiles run 3 x 3, 57 tiles 3 x 5)
 @pytest.mark.parametrize("L,F,cin,cout,n", [(5, 1100, 3, 1, 257), (5, 1494, 3, 1, 100), (3, 1800, 2, 3, 65), (4, 2048, 3, 1, 130), (3, 2100, 3, 1, 33),
-                                             (3, 3000, 3, 1, 31), (3, 4096, 3, 1, 40), (2, 1500, 3, 1, 77), (3, 1025, 3, 2, 9000)])
+                                             (3, 3000, 3, 1, 31), (3, 4096, 3, 1, 40), (2, 1500, 3, 1, 77), (3, 1025, 3, 2, 9000), (4, 1100, 3, 1, 1)])
 def test_forward_above_1024_vs_oracle(L, F, cin, cout, n):
     m, d, p = make_net(L, F, 20.0, cin, cout, seed=L * 100 + F)
     x = np.random.default_rng(F).uniform(-1, 1, size=(n, cin)).astype(np.float32)
@@ -37,7 +38,7 @@ def test_forward_above_1024_vs_oracle(L, F, cin, cout, n):
 
 @pytest.mark.parametrize("L,F,cin,cout,n,oa", [(5, 1100, 3, 1, 300, False), (5, 1494, 3, 1, 200, False), (4, 2048, 3, 1, 130, False),
                                                 (3, 1800, 2, 3, 100, False), (4, 1200, 3, 1, 333, True), (3, 2100, 3, 2, 70, False),
-                                                (3, 4096, 3, 1, 40, False), (2, 1500, 3, 1, 129, False), (3, 1056, 3, 1, 8300, False)])
+                                                (3, 4096, 3, 1, 40, False), (2, 1500, 3, 1, 129, False), (3, 1056, 3, 1, 8300, False), (4, 1100, 3, 1, 1, False)])
 def test_train_step_above_1024_vs_oracle(L, F, cin, cout, n, oa):
     m, d, p = make_net(L, F, 20.0, cin, cout, oa, seed=L * 10 + F)
     rng = np.random.default_rng(F + n)
