@@ -235,6 +235,9 @@ static FusedPlan fused_plan(const brief_siren_desc &d, int64_t n, bool train)
     p.grid = p.pers_wgs + (int)(tiles - p.pers_tiles);
     return p;
 }
+#ifndef BRIEF_WGRAD_ROUNDS
+#define BRIEF_WGRAD_ROUNDS 1
+#endif
 static int wgrad_splits(const brief_siren_desc &d, int64_t n)
 {
     const int hidden = d.layers - 2;
@@ -245,13 +248,27 @@ static int wgrad_splits(const brief_siren_desc &d, int64_t n)
     if (brief_nt(d) > 32) {
         // above 1024 features one K split already has about as many quadrant blocks as the device has CUs (4x2048: 192, 4x1494: 108): take the
         // split count (<= 16) whose blocks fill whole rounds best.  A split more costs k_reduce one more slab per layer (FP^2 floats: 9 MB at 1 494
-        // features = ~7 us at the 4 TB/s it reads) against a k_wgrad of ~12 ms: 0.001 of the launch per split in this model — 4x1494 takes 7 splits
+        // features = ~7 us at the 4 TB/s it reads) against a k_wgrad of ~12 ms: priced at 0.001 per split in this model — 4x1494 takes 7 splits
         // (756 workgroups = 2.95 rounds) where 2 (216 = 0.84 of a round) cost it 14 % of the launch
         const int64_t B = (int64_t)hidden * wgrad_nq(brief_nt(d)) * wgrad_nq(brief_nt(d));
         double best = 1e30;
         for (int64_t c = 1; c <= 16; ++c) {
             const double cost = (double)((c * B + kWgradBlocks - 1) / kWgradBlocks) / (double)c + 0.001 * (double)c;
             if (cost < best - 1e-9) { best = cost; s = c; }
+        }
+    }
+    else if (wgrad_nq(brief_nt(d)) >= 2 && BRIEF_WGRAD_ROUNDS) {
+        // run-time widths up to 1024 features: one round of s B <= CUs workgroups can leave CUs idle (25 .. 32 tiles, three hidden layers: 5 x 48 = 240 of
+        // 256; eight sine layers of 1024: 2 x 112 = 224); a multiple-round split count is taken when it fills the rounds at least 2 % better.  A split more
+        // costs k_reduce one slab per layer (FP^2 floats at ~4 TB/s: 1 us at 1024 features) against one quadrant workgroup's whole-K time (~25 ms):
+        // 0.0001 of the unit this cost is counted in.  Measured (tools/ab_step.sh): 4x1024 14.89 -> 14.63 ms, 4x896 11.70 -> 11.48, 4x800 10.27 -> 10.08
+        const int64_t B = (int64_t)hidden * wgrad_nq(brief_nt(d)) * wgrad_nq(brief_nt(d));
+        const double base = 1.0 / (double)s + 0.0001 * (double)s;
+        double best = base;
+        const int64_t cmax = 4 * s > 16 ? 4 * s : 16;
+        for (int64_t c = s + 1; c <= cmax && c <= 64; ++c) {
+            const double cost = (double)((c * B + kWgradBlocks - 1) / kWgradBlocks) / (double)c + 0.0001 * (double)c;
+            if (cost < best - 1e-9 && cost < 0.98 * base) { best = cost; s = c; }
         }
     }
     if (s > nchunks) s = nchunks;
