@@ -259,16 +259,17 @@ static int wgrad_splits(const brief_siren_desc &d, int64_t n)
     }
     else if (wgrad_nq(brief_nt(d)) >= 2 && BRIEF_WGRAD_ROUNDS) {
         // run-time widths up to 1024 features: one round of s B <= CUs workgroups can leave CUs idle (25 .. 32 tiles, three hidden layers: 5 x 48 = 240 of
-        // 256; eight sine layers of 1024: 2 x 112 = 224); a multiple-round split count is taken when it fills the rounds at least 2 % better.  A split more
+        // 256; eight sine layers of 1024: 2 x 112 = 224); a multiple-round split count is taken when it fills the rounds at least 1.5 % better.  A split more
         // costs k_reduce one slab per layer (FP^2 floats at ~4 TB/s: 1 us at 1024 features) against one quadrant workgroup's whole-K time (~25 ms):
-        // 0.0001 of the unit this cost is counted in.  Measured (tools/ab_step.sh): 4x1024 14.89 -> 14.63 ms, 4x896 11.70 -> 11.48, 4x800 10.27 -> 10.08
+        // 0.0001 of the unit this cost is counted in.  Measured (tools/ab_step.sh): 4x1024 14.89 -> 14.63 ms, 4x896 11.70 -> 11.48, 4x800 10.27 -> 10.08;
+        // 17 .. 24 tiles (9 -> 28 splits = 756 workgroups = 2.95 rounds): 4x527 4.677 -> 4.649, 4x640 6.287 -> 6.242, 4x768 unchanged
         const int64_t B = (int64_t)hidden * wgrad_nq(brief_nt(d)) * wgrad_nq(brief_nt(d));
         const double base = 1.0 / (double)s + 0.0001 * (double)s;
         double best = base;
         const int64_t cmax = 4 * s > 16 ? 4 * s : 16;
         for (int64_t c = s + 1; c <= cmax && c <= 64; ++c) {
             const double cost = (double)((c * B + kWgradBlocks - 1) / kWgradBlocks) / (double)c + 0.0001 * (double)c;
-            if (cost < best - 1e-9 && cost < 0.98 * base) { best = cost; s = c; }
+            if (cost < best - 1e-9 && cost < 0.985 * base) { best = cost; s = c; }
         }
     }
     if (s > nchunks) s = nchunks;
