@@ -102,6 +102,9 @@ struct DevState {
     bool aux_init;                      // the side stream of the bf16 overlap plan (train_step_impl) and its fork / join events
     hipStream_t aux;
     hipEvent_t aux_fork, aux_join;
+    bool aux2_init;                     // ... and of the fp32 tail plan (fused_tail_plan)
+    hipStream_t aux2;
+    hipEvent_t aux2_fork, aux2_join;
     hipEvent_t *prof_ev;                // [2 * kProfSlots]
     int nattr;
     const void *attr_fn[256];           // kernels whose hipFuncAttributeMaxDynamicSharedMemorySize was set on this device
@@ -238,32 +241,80 @@ static FusedPlan fused_plan(const brief_siren_desc &d, int64_t n, bool train)
 #ifndef BRIEF_WGRAD_ROUNDS
 #define BRIEF_WGRAD_ROUNDS 1
 #endif
-static int wgrad_splits(const brief_siren_desc &d, int64_t n)
+#ifndef BRIEF_TAIL_PLAN
+#define BRIEF_TAIL_PLAN 1
+#endif
+#ifndef BRIEF_TAIL_LEAN
+#define BRIEF_TAIL_LEAN 0
+#endif
+#ifndef BRIEF_TAIL_MIN_SPLITS
+#define BRIEF_TAIL_MIN_SPLITS 6
+#endif
+#ifndef BRIEF_TAIL_MIN_ROUNDS
+#define BRIEF_TAIL_MIN_ROUNDS 3
+#endif
+// The tail plan of the wide fp32 nets (9 tiles and more: k_lean with two or one workgroup per CU, k_wide).  A 100 000-sample batch is 3 125 tiles; with G resident
+// workgroups the last round of the fused kernel holds 3 125 mod G tiles (53 for G = 256 or 512) and the other CUs idle for a whole tile time — 1 / 12.2 of the
+// launch at one workgroup per CU, i.e. ~6 % of it.  Nothing in k_wgrad's work on the BODY's chunks depends on those tiles, so:
+//     stream:        fused body (whole rounds) ─┬─ fused tail (the last tiles) ─ k_wgrad over the tail's chunks (one more K split) ─┬─ k_reduce
+//     side stream:                              └─ k_wgrad over the body's chunks ───────────────────────────────────────────────────┘
+// k_wgrad's workgroups fill the CUs the tail leaves free and, being several rounds of short workgroups, take over the tail's CUs as they become free.  (At 8 tiles —
+// the headline — this loses: its k_wgrad is ONE round of 255 one-per-CU workgroups, and the slabs three rounds would need cost k_reduce more than the tail: DESIGN.md.)
+// Slabs are summed in slab order; the plan is a function of the job alone, so results stay bit-reproducible.
+// Measured (tools/ab_step.sh, three interleaved rounds, profiles/r05_tail_plan.md): 4x1494 33.85 -> 32.68 ms (+3.5 %), 4x1100 19.63 -> 19.45 (+0.9 %); where the body's
+// k_wgrad has FEW long workgroups the end of the step is quantised by its rounds and the plan loses (4x1800 52.16 -> 52.65, 4x2048 59.45 -> 59.70: 4 splits of 192),
+// and k_lean's nets (9 .. 32 tiles) gain nothing at their split counts (4x1024 14.58 -> 14.62, 4x512 3.90 -> 4.15 with the 64 splits three rounds need): the plan is
+// taken for k_wide when the body splits at least 6 ways.
+struct TailPlan { bool on; int grid_body, grid_tail; int64_t tiles_body; };
+static int wgrad_split_rule(const brief_siren_desc &d, int64_t nchunks, int min_rounds);
+static TailPlan fused_tail_plan(const brief_siren_desc &d, int64_t n)
+{
+    TailPlan p;
+    p.on = false; p.grid_body = p.grid_tail = 0; p.tiles_body = 0;
+    if (!BRIEF_TAIL_PLAN || d.precision != BRIEF_PREC_F32 || d.layers - 2 < 1) return p;
+    const int nt = brief_nt(d);
+    if (!(brief_use_wide(d) || (BRIEF_TAIL_LEAN && brief_use_lean(d, true) && nt >= 9))) return p;
+    const int64_t tiles = (n + 31) / 32;
+    const int G = fused_grid(d, n, true);
+    const int64_t full = tiles / G * G, rem = tiles - full;
+    if (full == 0 || rem == 0 || rem * 4 > 3 * (int64_t)G) return p;      // (a last round that is three quarters full has nothing to give)
+    if (wgrad_split_rule(d, full, BRIEF_TAIL_MIN_ROUNDS) < BRIEF_TAIL_MIN_SPLITS) return p;
+    p.on = true; p.grid_body = G; p.grid_tail = (int)rem; p.tiles_body = full;
+    return p;
+}
+// K splits of k_wgrad over `nchunks` 32-sample chunks.  min_rounds > 1 (the tail plan): at least that many rounds of quadrant workgroups
+static int wgrad_split_rule(const brief_siren_desc &d, int64_t nchunks, int min_rounds)
 {
     const int hidden = d.layers - 2;
     if (hidden <= 0) return 0;
-    const int64_t nchunks = brief_npad_d(d, n) / 32;
-    int64_t s = kWgradBlocks / (hidden * wgrad_nq(brief_nt(d)) * wgrad_nq(brief_nt(d)));
+    const int nq = wgrad_nq(brief_nt(d));
+    const int64_t B = (int64_t)hidden * nq * nq;      // quadrant workgroups of one K split
+    int64_t s = kWgradBlocks / B;
     if (s < 1) s = 1;
-    if (brief_nt(d) > 32) {
+    if (min_rounds > 1) {
+        double best = 1e30;
+        for (int64_t c = 1; c <= 64; ++c) {
+            const int64_t rounds = (c * B + kWgradBlocks - 1) / kWgradBlocks;
+            if (rounds < min_rounds && c < 64) continue;
+            const double cost = (double)rounds / (double)c + 0.0001 * (double)c;
+            if (cost < best - 1e-9) { best = cost; s = c; }
+        }
+    } else if (brief_nt(d) > 32) {
         // above 1024 features one K split already has about as many quadrant blocks as the device has CUs (4x2048: 192, 4x1494: 108): take the
         // split count (<= 16) whose blocks fill whole rounds best.  A split more costs k_reduce one more slab per layer (FP^2 floats: 9 MB at 1 494
         // features = ~7 us at the 4 TB/s it reads) against a k_wgrad of ~12 ms: priced at 0.001 per split in this model — 4x1494 takes 7 splits
         // (756 workgroups = 2.95 rounds) where 2 (216 = 0.84 of a round) cost it 14 % of the launch
-        const int64_t B = (int64_t)hidden * wgrad_nq(brief_nt(d)) * wgrad_nq(brief_nt(d));
         double best = 1e30;
         for (int64_t c = 1; c <= 16; ++c) {
             const double cost = (double)((c * B + kWgradBlocks - 1) / kWgradBlocks) / (double)c + 0.001 * (double)c;
             if (cost < best - 1e-9) { best = cost; s = c; }
         }
-    }
-    else if (wgrad_nq(brief_nt(d)) >= 2 && BRIEF_WGRAD_ROUNDS) {
+    } else if (nq >= 2 && BRIEF_WGRAD_ROUNDS) {
         // run-time widths up to 1024 features: one round of s B <= CUs workgroups can leave CUs idle (25 .. 32 tiles, three hidden layers: 5 x 48 = 240 of
         // 256; eight sine layers of 1024: 2 x 112 = 224); a multiple-round split count is taken when it fills the rounds at least 1.5 % better.  A split more
         // costs k_reduce one slab per layer (FP^2 floats at ~4 TB/s: 1 us at 1024 features) against one quadrant workgroup's whole-K time (~25 ms):
         // 0.0001 of the unit this cost is counted in.  Measured (tools/ab_step.sh): 4x1024 14.89 -> 14.63 ms, 4x896 11.70 -> 11.48, 4x800 10.27 -> 10.08;
         // 17 .. 24 tiles (9 -> 28 splits = 756 workgroups = 2.95 rounds): 4x527 4.677 -> 4.649, 4x640 6.287 -> 6.242, 4x768 unchanged
-        const int64_t B = (int64_t)hidden * wgrad_nq(brief_nt(d)) * wgrad_nq(brief_nt(d));
         const double base = 1.0 / (double)s + 0.0001 * (double)s;
         double best = base;
         const int64_t cmax = 4 * s > 16 ? 4 * s : 16;
@@ -274,6 +325,14 @@ static int wgrad_splits(const brief_siren_desc &d, int64_t n)
     }
     if (s > nchunks) s = nchunks;
     return (int)s;
+}
+// total K splits (slabs per layer) of a train step: under the tail plan the body's splits + one for the tail's chunks
+static int wgrad_splits(const brief_siren_desc &d, int64_t n)
+{
+    if (d.layers - 2 <= 0) return 0;
+    const TailPlan tp = fused_tail_plan(d, n);
+    if (tp.on) return wgrad_split_rule(d, tp.tiles_body, BRIEF_TAIL_MIN_ROUNDS) + 1;
+    return wgrad_split_rule(d, brief_npad_d(d, n) / 32, 1);
 }
 
 // narrow nets (F <= 64, at most 7 hidden layers) train through k_small: no stash, no k_wgrad.
@@ -408,10 +467,10 @@ static Ws16 ws16_layout(const brief_siren_desc &d, int64_t n)
 }
 
 struct WsLayout { int64_t z, dd, rec, slabs, table, img, total; };
-// per-wave records of the fused kernel (k_wide: one workgroup per CU; everything else: up to kRecWgsPerCu)
+// per-wave records of the fused kernel (k_wide: one workgroup per CU + the tail launch's; everything else: up to kRecWgsPerCu)
 static int64_t rec_region_floats(const brief_siren_desc &d)
 {
-    return (int64_t)kCUs * (brief_use_wide(d) ? 1 : kRecWgsPerCu) * 4 * brief_rec_floats(brief_nt(d));
+    return (int64_t)kCUs * (brief_use_wide(d) ? 2 : kRecWgsPerCu) * 4 * brief_rec_floats(brief_nt(d));
 }
 static WsLayout ws_layout(const brief_siren_desc &d, int64_t n)
 {
@@ -482,7 +541,7 @@ static void fill_grid(GridArgs &g, const brief_grid_desc *grid)
 template <typename KP, typename A>
 static inline void launch_timed(KP kern, int grid, int block, size_t lds, hipStream_t st, const A &arg, hipEvent_t e0, hipEvent_t e1)
 {
-    if (e0) hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), (uint32_t)lds, st, e0, e1, 0, arg);
+    if (e0 || e1) hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), (uint32_t)lds, st, e0, e1, 0, arg);
     else hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, st, arg);
 }
 
@@ -812,7 +871,8 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
     }
     const bool small = use_small(*d);
     const FusedPlan fp = fused_plan(*d, batch->n, true);
-    const int grid1 = small ? small_grid(*d, batch->n) : fp.grid;
+    const TailPlan tp = small ? TailPlan{false, 0, 0, 0} : fused_tail_plan(*d, batch->n);      // wide fp32 nets: the last round's tiles on a side stream
+    const int grid1 = small ? small_grid(*d, batch->n) : (tp.on ? tp.grid_body + tp.grid_tail : fp.grid);      // (= workgroup records)
     const int nsplit = small ? (d->layers > 2 ? grid1 : 0) : wgrad_splits(*d, batch->n);
     const float inv_count = (float)(1.0 / ((double)batch->n * d->cout));
 
@@ -866,7 +926,28 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
         BRIEF_CASE(2, 1) BRIEF_CASE(2, 3) BRIEF_CASE(2, 5) BRIEF_CASE(2, 7)
 #undef BRIEF_CASE
         HIP_TRY(hipGetLastError());
-    } else if (int rc = launch_fused<true>(fa, grid1, st, pe0, pe1)) return rc;
+    } else if (!tp.on) {
+        if (int rc = launch_fused<true>(fa, grid1, st, pe0, pe1)) return rc;
+    }
+    hipStream_t side = st;
+    if (tp.on) {
+        DevState *ds = dev_state();
+        if (!ds) return fail(BRIEF_ERR_INVALID, "out of host memory");
+        if (!ds->aux2_init) {
+            HIP_TRY(hipStreamCreateWithFlags(&ds->aux2, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&ds->aux2_fork, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&ds->aux2_join, hipEventDisableTiming));
+            ds->aux2_init = true;
+        }
+        side = ds->aux2;
+        fa.n_begin = 0; fa.n_end = tp.tiles_body * 32; fa.rec_base = 0;
+        if (int rc = launch_fused<true>(fa, tp.grid_body, st, pe0, nullptr)) return rc;
+        HIP_TRY(hipEventRecord(ds->aux2_fork, st));
+        HIP_TRY(hipStreamWaitEvent(side, ds->aux2_fork, 0));
+        // the tail stays on the caller's stream, right behind the body (its workgroups are placed first); the body's k_wgrad arrives through the event a moment later
+        fa.n_begin = tp.tiles_body * 32; fa.n_end = 0; fa.rec_base = tp.grid_body;
+        if (int rc = launch_fused<true>(fa, tp.grid_tail, st, nullptr, pe1)) return rc;      // (the profile pair: body start .. tail end)
+    }
     if (prof) ++g_prof_n;
 
     if (!small && nsplit > 0) {
@@ -874,23 +955,30 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
         memset(&wa, 0, sizeof(wa));
         wa.d = *d; wa.Z = fa.Z; wa.D = fa.D; wa.npad = fa.npad; wa.nsplit = nsplit; wa.slabs = ws + wl.slabs;
         wa.stamps = ws + wl.rec + rec_region_floats(*d) - 256 * 8 * 8;   // tail of the record region (diagnostics)
-        const int blocks = nsplit * (d->layers - 2) * wgrad_nq(nt) * wgrad_nq(nt);
+        // K range and slabs of a launch: every chunk into nsplit slabs, or (tail plan) the body's chunks into nsplit - 1 and the tail's into the last one
+        const int nsA = tp.on ? nsplit - 1 : nsplit;
+        wa.kb_lo = 0; wa.kb_hi = tp.on ? tp.tiles_body : fa.npad / 32; wa.split_lo = 0; wa.nsplit_here = nsA;
+        const int per_split = (d->layers - 2) * wgrad_nq(nt) * wgrad_nq(nt);
+        for (int part = 0; part < (tp.on ? 2 : 1); ++part) {
+        hipStream_t wst = part || !tp.on ? st : side;
+        if (part) { wa.kb_lo = tp.tiles_body; wa.kb_hi = fa.npad / 32; wa.split_lo = nsA; wa.nsplit_here = 1; }
+        const int blocks = wa.nsplit_here * per_split;
         if (d->precision == BRIEF_PREC_BF16X3) {
             for (int rep = 0; rep < g_wgrad_repeat; ++rep)      // BRIEF_WGRAD_REPEAT (diagnostics): the launch is idempotent
-                hipLaunchKernelGGL(k_wgrad_x3, dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(8), st, wa);
+                hipLaunchKernelGGL(k_wgrad_x3, dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(8), wst, wa);
         } else
 #define BRIEF_CASE(NTV)                                                                                    \
     case NTV:                                                                                              \
-        hipLaunchKernelGGL((k_wgrad<NTV>), dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(NTV), st, wa); \
+        hipLaunchKernelGGL((k_wgrad<NTV>), dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(NTV), wst, wa); \
         break;
         if (nt > 8) {
             // run-time width: ceil(nt / 8) quadrants per side of QT = ceil(nt / quadrants) tiles (the last row / column may be short)
             const int qt = (nt + wgrad_nq(nt) - 1) / wgrad_nq(nt);
             switch (qt) {
-            case 5: hipLaunchKernelGGL((k_wgrad<0, 5>), dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(5), st, wa); break;
-            case 6: hipLaunchKernelGGL((k_wgrad<0, 6>), dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(6), st, wa); break;
-            case 7: hipLaunchKernelGGL((k_wgrad<0, 7>), dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(7), st, wa); break;
-            case 8: hipLaunchKernelGGL((k_wgrad<0, 8>), dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(8), st, wa); break;
+            case 5: hipLaunchKernelGGL((k_wgrad<0, 5>), dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(5), wst, wa); break;
+            case 6: hipLaunchKernelGGL((k_wgrad<0, 6>), dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(6), wst, wa); break;
+            case 7: hipLaunchKernelGGL((k_wgrad<0, 7>), dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(7), wst, wa); break;
+            case 8: hipLaunchKernelGGL((k_wgrad<0, 8>), dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(8), wst, wa); break;
             default: return fail(BRIEF_ERR_INVALID, "unsupported width");
             }
         } else
@@ -900,6 +988,11 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
         }
 #undef BRIEF_CASE
         HIP_TRY(hipGetLastError());
+        }
+    }
+    if (tp.on) {
+        HIP_TRY(hipEventRecord(dev_state()->aux2_join, side));
+        HIP_TRY(hipStreamWaitEvent(st, dev_state()->aux2_join, 0));
     }
     hipLaunchKernelGGL(k_reduce, dim3(nb_hidden + nb_skinny), dim3(rthreads), 0, st, ra, nb_hidden);
     HIP_TRY(hipGetLastError());
