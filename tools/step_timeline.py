@@ -1,7 +1,8 @@
 """timeline of ONE optimizer step from a rocprofv3 --kernel-trace csv: every dispatch's start / end relative to the step's first kernel, and the
 stream (queue) it ran on — what shows whether launches on different streams overlap.
     rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl -o p -- python3 bench.py --config c3 --precision bf16 --steps 10 --warmup 2 --preroll 20 --preroll-seconds 0 --no-cpu-baseline --no-psnr --no-extras
-    python tools/step_timeline.py gpurun_out/tl [first-kernel-substring] [step-index-from-the-end]"""
+    python tools/step_timeline.py gpurun_out/tl [first-kernel-substring] [step-index-from-the-end] [min-grid-of-the-first-kernel]
+(the last argument: when a step launches the first kernel twice — body and tail — a step starts at the launch whose grid is at least that many threads)"""
 import csv
 import glob
 import sys
@@ -12,7 +13,8 @@ back = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 path = sorted(glob.glob(d + "/**/*kernel_trace.csv", recursive=True))[-1]
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-starts = [i for i, r in enumerate(rows) if first in r["Kernel_Name"]]
+min_grid = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+starts = [i for i, r in enumerate(rows) if first in r["Kernel_Name"] and int(r.get("Grid_Size", r.get("Grid_Size_X", "0")) or 0) >= min_grid]
 i0 = starts[-back]
 i1 = starts[-back + 1] if back > 1 else len(rows)
 t0 = int(rows[i0]["Start_Timestamp"])
