@@ -187,6 +187,8 @@ static const int g_diag = env_int("BRIEF_DIAG", 0, 0, 255);
 static const int g_x3_decode = env_int("BRIEF_X3_DECODE", 1, 0, 1);      // 0 (diagnostics): BRIEF_PREC_BF16X3 nets are evaluated by the f32 forward kernel
 static const int g_wgrad_repeat = env_int("BRIEF_WGRAD_REPEAT", 1, 1, 8);      // diagnostics: k_wgrad_x3 launched this many times per step (reads of data that k_fused has just written vs data at rest)
 static const int g_reduce_sg_big = env_int("BRIEF_REDUCE_SG_BIG", 4, 1, 64);
+static const int g_reduce_part = env_int("BRIEF_REDUCE_PART", 0, 0, 2);        // diagnostics: 1 / 2 = launch only k_reduce's hidden-parameter / skinny blocks (what each costs alone; results are then incomplete)
+static const int g_reduce_vec = env_int("BRIEF_REDUCE_VEC", 1, 0, 1);          // diagnostics: 0 = one hidden parameter per k_reduce thread everywhere
 static const int g_reduce_sg_small = env_int("BRIEF_REDUCE_SG", 0, 0, 64);      // diagnostics: k_reduce threads per hidden parameter behind k_small (power of two; 0 = by slab count)
 // samples one workgroup tile covers: 32 per sample sub-tile; the split-precision TRAIN kernel walks 64-sample tiles
 static int64_t fused_wg_samples(const brief_siren_desc &d, bool train)
@@ -904,8 +906,15 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
     if (upd) { ra.update = 1; ra.opt = upd->opt; ra.params = upd->params; ra.s1 = upd->s1; ra.s2 = upd->s2; ra.pk = upd->pk; }
     const int64_t l0_count = (int64_t)d->features * d->cin + d->features;
     const int64_t hcount = brief_canon_head_off(*d) - l0_count;
-    const int64_t skinny = l0_count + (int64_t)d->cout * d->features + d->cout + 1;   // + the loss
-    const int ppb = rthreads / ra.sgroups;             // hidden parameters per k_reduce block
+    const int64_t skinny = d->features + (int64_t)d->cout * ((d->features + 3) / 4) + 2;   // groups of four record slots (reduce_body): first-layer rows, head quads, head biases, the loss
+    // fp32 nets behind k_wgrad: 4 / 2 consecutive parameters per thread where the width is a multiple (reduce_hidden_vec)
+    ra.vec = (!small && g_reduce_vec && d->precision == BRIEF_PREC_F32 && rthreads * 4 <= 1024) ? (d->features % 4 == 0 ? 4 : (d->features % 2 == 0 ? 2 : 0)) : 0;
+    {   // (caller-owned buffers: fall back to narrower accesses when one is not aligned for them)
+        const uintptr_t bits = (uintptr_t)grads | (uintptr_t)ra.params | (uintptr_t)ra.s1 | (uintptr_t)ra.s2 | (uintptr_t)ra.pk | (uintptr_t)ra.slabs;
+        while (ra.vec > 1 && bits % (sizeof(float) * ra.vec) != 0) ra.vec /= 2;
+        if (ra.vec == 1) ra.vec = 0;
+    }
+    const int ppb = rthreads / ra.sgroups * (ra.vec ? ra.vec : 1);             // hidden parameters per k_reduce block
     const int nb_hidden = (int)((hcount + ppb - 1) / ppb);
     const int wpb = rthreads / 64;                     // skinny items (one wave each) per block
     const int nb_skinny = (int)((skinny + wpb - 1) / wpb);
@@ -994,6 +1003,9 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
         HIP_TRY(hipEventRecord(dev_state()->aux2_join, side));
         HIP_TRY(hipStreamWaitEvent(st, dev_state()->aux2_join, 0));
     }
+    if (g_reduce_part == 1) hipLaunchKernelGGL(k_reduce, dim3(nb_hidden), dim3(rthreads), 0, st, ra, nb_hidden);          // diagnostics: the hidden-parameter blocks alone
+    else if (g_reduce_part == 2) hipLaunchKernelGGL(k_reduce, dim3(nb_skinny), dim3(rthreads), 0, st, ra, 0);         // diagnostics: the skinny blocks alone
+    else
     hipLaunchKernelGGL(k_reduce, dim3(nb_hidden + nb_skinny), dim3(rthreads), 0, st, ra, nb_hidden);
     HIP_TRY(hipGetLastError());
     return 0;
