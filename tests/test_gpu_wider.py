@@ -38,7 +38,11 @@ def test_forward_above_1024_vs_oracle(L, F, cin, cout, n):
 
 @pytest.mark.parametrize("L,F,cin,cout,n,oa", [(5, 1100, 3, 1, 300, False), (5, 1494, 3, 1, 200, False), (4, 2048, 3, 1, 130, False),
                                                 (3, 1800, 2, 3, 100, False), (4, 1200, 3, 1, 333, True), (3, 2100, 3, 2, 70, False),
-                                                (3, 4096, 3, 1, 40, False), (2, 1500, 3, 1, 129, False), (3, 1056, 3, 1, 8300, False), (4, 1100, 3, 1, 1, False)])
+                                                (3, 4096, 3, 1, 40, False), (2, 1500, 3, 1, 129, False), (3, 1056, 3, 1, 8300, False), (4, 1100, 3, 1, 1, False),
+                                                # more tiles than the 256 resident workgroups and a ragged last round: the TAIL PLAN (brief_hip.hip fused_tail_plan: the last
+                                                # round as its own launch, the body's k_wgrad on a side stream, the tail's chunks as one more K split) — 282 = 256 + 26 tiles
+                                                # with 10 + 1 splits, 375 = 256 + 119 with 7 + 1 (8300 samples above: 256 + 4)
+                                                (5, 1100, 3, 1, 9000, False), (4, 1300, 2, 2, 12000, False)])
 def test_train_step_above_1024_vs_oracle(L, F, cin, cout, n, oa):
     m, d, p = make_net(L, F, 20.0, cin, cout, oa, seed=L * 10 + F)
     rng = np.random.default_rng(F + n)
