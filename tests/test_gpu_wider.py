@@ -160,3 +160,34 @@ def test_cli_default_yaml_on_a_1024_cube_solves_to_1494_features_and_runs(tmp_pa
     psnr = float(vals[head.index("psnr")])
     print("default.yaml on 1024^3: F = 1494, 60 steps, psnr %.2f dB" % psnr)
     assert psnr > 25.0                                                                   # 60 steps only: a floor, not a quality claim
+
+
+@pytest.mark.parametrize("F,n,prec", [(1100, 9000, "fp32"), (512, 100000, "bf16")])
+def test_side_stream_plans_survive_graph_capture(F, n, prec):
+    """the tail plan of the wide fp32 nets and the bf16 overlap plan fork part of a train step onto the library's own side stream and join it
+    back by events: captured into a graph on torch's capture stream the fork / join become graph edges — three replays of one
+    captured step give the gradients of eager steps, bit for bit"""
+    dims = (64, 64, 64)
+    torch.manual_seed(1)
+    tv = torch.rand(64 ** 3, 1, device=DEV) * 100
+    idx = torch.randint(0, 64 ** 3, (n,), device=DEV)
+
+    def net():
+        torch.manual_seed(7)
+        return SIREN(features=F, layers=4, w0=20, precision=prec).to(DEV)
+
+    a = net()
+    for _ in range(2):
+        a.train_step(n, tv, idx=idx, grid=(dims, -1.0, 1.0))
+    b = net()
+    b.train_step(n, tv, idx=idx, grid=(dims, -1.0, 1.0))      # outside the capture: kernel attributes, the side stream, the workspace
+    torch.cuda.synchronize()
+    b.grads.zero_()
+    g, s = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            b.train_step(n, tv, idx=idx, grid=(dims, -1.0, 1.0))
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    assert float(a.grads.abs().max()) > 0 and torch.equal(a.grads, b.grads)
