@@ -191,3 +191,4 @@ def test_side_stream_plans_survive_graph_capture(F, n, prec):
         g.replay()
     torch.cuda.synchronize()
     assert float(a.grads.abs().max()) > 0 and torch.equal(a.grads, b.grads)
+

@@ -1,7 +1,7 @@
 """Is the falling PSNR of WIDE nets at lr = 1e-3 (profiles/r05_rate_distortion.md: 4x768 34.7 dB, 4x1024 25.4 dB after 20 000 steps against 41 dB at 384 features)
 the model's training dynamics or this library's?  The same net, initial weights, optimizer (torch.optim.Adamax, lr 1e-3) and sampler statistics in PLAIN PyTorch
 (nn.Linear + torch.sin on the GPU through rocBLAS, autograd) beside the fused path, on one textured 256^3 volume; and the fused path again at lr / 4.
-    python tools/wide_dynamics_check.py [F] [steps] [nolow]"""
+    python tools/wide_dynamics_check.py [F] [steps] [nolow|low] [edge]"""
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, '.')
@@ -12,7 +12,7 @@ from brief_pytorch_amd.synthetic import make_volume_torch
 
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 768
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
-E, n, L, w0 = 256, 100000, 5, 20.0
+E, n, L, w0 = (int(sys.argv[4]) if len(sys.argv) > 4 else 256), 100000, 5, 20.0
 dims, vox = (E, E, E), E ** 3
 vol = make_volume_torch(dims, seed=42, detail=64)
 vf = vol.to(torch.int32).to(torch.float32)
@@ -62,5 +62,5 @@ def plain():
 print("4x%d on a textured %d^3 volume, PSNR dB after %d / %d / %d steps" % (F, E, steps // 3, 2 * (steps // 3), steps))
 print("  fused path, Adamax lr 1e-3   : %s" % " ".join("%.2f" % v for v in fused(1e-3)), flush=True)
 print("  plain PyTorch, Adamax lr 1e-3: %s" % " ".join("%.2f" % v for v in plain()), flush=True)
-if len(sys.argv) <= 3:
+if len(sys.argv) <= 3 or sys.argv[3] == 'low':
     print("  fused path, Adamax lr 2.5e-4 : %s" % " ".join("%.2f" % v for v in fused(2.5e-4)), flush=True)
