@@ -751,6 +751,38 @@ struct UpdatePayload { OptimScalars opt; float *params, *s1, *s2, *pk; };
 // what one narrow-net step launches, as data: brief_multi_fit collects these for a group of jobs and launches them together
 struct SmallStepPlan { FusedArgs fa; ReduceArgs ra; int grid1, nb_hidden, nb_reduce, nt, hb; };
 
+// the weight-gradient GEMM of the hidden layers: `blocks` = K splits of this launch x hidden layers x quadrants
+static int launch_wgrad(const brief_siren_desc &d, const WgradArgs &wa, int blocks, hipStream_t st)
+{
+    const int nt = brief_nt(d);
+    if (d.precision == BRIEF_PREC_BF16X3) {
+        for (int rep = 0; rep < g_wgrad_repeat; ++rep)      // BRIEF_WGRAD_REPEAT (diagnostics): the launch is idempotent
+            hipLaunchKernelGGL(k_wgrad_x3, dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(8), st, wa);
+    } else if (nt > 8) {
+        // run-time width: ceil(nt / 8) quadrants per side of QT = ceil(nt / quadrants) tiles (the last row / column may be short)
+        const int qt = (nt + wgrad_nq(nt) - 1) / wgrad_nq(nt);
+        switch (qt) {
+        case 5: hipLaunchKernelGGL((k_wgrad<0, 5>), dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(5), st, wa); break;
+        case 6: hipLaunchKernelGGL((k_wgrad<0, 6>), dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(6), st, wa); break;
+        case 7: hipLaunchKernelGGL((k_wgrad<0, 7>), dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(7), st, wa); break;
+        case 8: hipLaunchKernelGGL((k_wgrad<0, 8>), dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(8), st, wa); break;
+        default: return fail(BRIEF_ERR_INVALID, "unsupported width");
+        }
+    } else {
+#define BRIEF_CASE(NTV)                                                                                    \
+    case NTV:                                                                                              \
+        hipLaunchKernelGGL((k_wgrad<NTV>), dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(NTV), st, wa); \
+        break;
+        switch (nt) {
+            BRIEF_CASE(1) BRIEF_CASE(2) BRIEF_CASE(3) BRIEF_CASE(4)
+            BRIEF_CASE(5) BRIEF_CASE(6) BRIEF_CASE(7) BRIEF_CASE(8)
+        }
+#undef BRIEF_CASE
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 static int train_step_impl(const brief_siren_desc *d, const float *packed, const brief_grid_desc *grid,
                            const brief_batch_desc *batch, int loss_kind, float thr, float beta,
                            float *grads, float *loss_out, float *yhat_out,
@@ -969,34 +1001,9 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
         wa.kb_lo = 0; wa.kb_hi = tp.on ? tp.tiles_body : fa.npad / 32; wa.split_lo = 0; wa.nsplit_here = nsA;
         const int per_split = (d->layers - 2) * wgrad_nq(nt) * wgrad_nq(nt);
         for (int part = 0; part < (tp.on ? 2 : 1); ++part) {
-        hipStream_t wst = part || !tp.on ? st : side;
-        if (part) { wa.kb_lo = tp.tiles_body; wa.kb_hi = fa.npad / 32; wa.split_lo = nsA; wa.nsplit_here = 1; }
-        const int blocks = wa.nsplit_here * per_split;
-        if (d->precision == BRIEF_PREC_BF16X3) {
-            for (int rep = 0; rep < g_wgrad_repeat; ++rep)      // BRIEF_WGRAD_REPEAT (diagnostics): the launch is idempotent
-                hipLaunchKernelGGL(k_wgrad_x3, dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(8), wst, wa);
-        } else
-#define BRIEF_CASE(NTV)                                                                                    \
-    case NTV:                                                                                              \
-        hipLaunchKernelGGL((k_wgrad<NTV>), dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(NTV), wst, wa); \
-        break;
-        if (nt > 8) {
-            // run-time width: ceil(nt / 8) quadrants per side of QT = ceil(nt / quadrants) tiles (the last row / column may be short)
-            const int qt = (nt + wgrad_nq(nt) - 1) / wgrad_nq(nt);
-            switch (qt) {
-            case 5: hipLaunchKernelGGL((k_wgrad<0, 5>), dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(5), wst, wa); break;
-            case 6: hipLaunchKernelGGL((k_wgrad<0, 6>), dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(6), wst, wa); break;
-            case 7: hipLaunchKernelGGL((k_wgrad<0, 7>), dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(7), wst, wa); break;
-            case 8: hipLaunchKernelGGL((k_wgrad<0, 8>), dim3(blocks), dim3(512), sizeof(float) * wgrad_lds_floats(8), wst, wa); break;
-            default: return fail(BRIEF_ERR_INVALID, "unsupported width");
-            }
-        } else
-        switch (nt) {
-            BRIEF_CASE(1) BRIEF_CASE(2) BRIEF_CASE(3) BRIEF_CASE(4)
-            BRIEF_CASE(5) BRIEF_CASE(6) BRIEF_CASE(7) BRIEF_CASE(8)
-        }
-#undef BRIEF_CASE
-        HIP_TRY(hipGetLastError());
+            if (part) { wa.kb_lo = tp.tiles_body; wa.kb_hi = fa.npad / 32; wa.split_lo = nsA; wa.nsplit_here = 1; }
+            // (tail plan: the body's chunks on the side stream, the tail's — behind the tail launch — on the caller's)
+            if (int rc = launch_wgrad(*d, wa, wa.nsplit_here * per_split, part || !tp.on ? st : side)) return rc;
         }
     }
     if (tp.on) {
@@ -1005,8 +1012,7 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
     }
     if (g_reduce_part == 1) hipLaunchKernelGGL(k_reduce, dim3(nb_hidden), dim3(rthreads), 0, st, ra, nb_hidden);          // diagnostics: the hidden-parameter blocks alone
     else if (g_reduce_part == 2) hipLaunchKernelGGL(k_reduce, dim3(nb_skinny), dim3(rthreads), 0, st, ra, 0);         // diagnostics: the skinny blocks alone
-    else
-    hipLaunchKernelGGL(k_reduce, dim3(nb_hidden + nb_skinny), dim3(rthreads), 0, st, ra, nb_hidden);
+    else hipLaunchKernelGGL(k_reduce, dim3(nb_hidden + nb_skinny), dim3(rthreads), 0, st, ra, nb_hidden);
     HIP_TRY(hipGetLastError());
     return 0;
 }
