@@ -249,6 +249,12 @@ static FusedPlan fused_plan(const brief_siren_desc &d, int64_t n, bool train)
 #ifndef BRIEF_TAIL_LEAN
 #define BRIEF_TAIL_LEAN 0
 #endif
+#ifndef BRIEF_TAIL_MODE_DEFAULT
+#define BRIEF_TAIL_MODE_DEFAULT 2
+#endif
+#ifndef BRIEF_TAIL_R
+#define BRIEF_TAIL_R 1.15      // measured (tools/width_sweep.py over r = 0.5 .. 2.0, diagnostics build): 1.1 .. 1.2 is the flat optimum at 320, 384, 448 and 512 features
+#endif
 #ifndef BRIEF_TAIL_MIN_SPLITS
 #define BRIEF_TAIL_MIN_SPLITS 6
 #endif
@@ -267,21 +273,67 @@ static FusedPlan fused_plan(const brief_siren_desc &d, int64_t n, bool train)
 // k_wgrad has FEW long workgroups the end of the step is quantised by its rounds and the plan loses (4x1800 52.16 -> 52.65, 4x2048 59.45 -> 59.70: 4 splits of 192),
 // and k_lean's nets (9 .. 32 tiles) gain nothing at their split counts (4x1024 14.58 -> 14.62, 4x512 3.90 -> 4.15 with the 64 splits three rounds need): the plan is
 // taken for k_wide when the body splits at least 6 ways.
-struct TailPlan { bool on; int grid_body, grid_tail; int64_t tiles_body; };
+//
+// UNEVEN form (mode 2).  The form above adds a K split and needs k_wgrad in many short workgroups.  What the late CUs really need is LESS WORK, not finer work: k_wgrad's
+// workgroups go to CUs in index order, the `rem` CUs the tail holds for T take the LAST ones — so the last n_short K splits are made shorter by the T they start late,
+//     k_norm = (chunks + n_short rho) / nsplit,   k_short = k_norm - rho,   rho = T in units of one workgroup's time per 32-sample chunk,
+// and their workgroups numbered last (split-major order).  The short splits also take the tail's own chunks (the end of the chunk range), so they are a launch of their own behind
+// the tail on the caller's stream while the normal splits start on the side stream behind the body: same slab count, same k_reduce, every CU ends together:
+//     stream:        fused body ─┬─ fused tail (rem workgroups, T) ─ k_wgrad, the n_short short splits ─┬─ k_reduce
+//     side stream:               └─ k_wgrad, the nsplit - n_short normal splits ───────────────────────┘
+// rho = r 2 (L - 2) nt^2 / QT^2 (a tile's forward + dgrad chains against one chunk of a QT x QT quadrant, both on four SIMDs), r = how much slower a SOLO tile runs than
+// k_wgrad's steady rate (BRIEF_TAIL_R, measured).
+struct TailPlan { int mode /* 0 off, 1 extra split, 2 uneven splits */; bool on; int grid_body, grid_tail; int64_t tiles_body; int ns, n_norm; int64_t kfix_n, kfix_s; };
 static int wgrad_split_rule(const brief_siren_desc &d, int64_t nchunks, int min_rounds);
+static const int g_tail_mode = env_int("BRIEF_TAIL_MODE", BRIEF_TAIL_MODE_DEFAULT, 0, 2);      // diagnostics: 0 no tail plan, 1 the extra-split form only, 2 uneven splits where eligible
+static const int g_tail_r = env_int("BRIEF_TAIL_R", 0, 0, 1000);                               // diagnostics: r in percent (0: the class's own)
 static TailPlan fused_tail_plan(const brief_siren_desc &d, int64_t n)
 {
     TailPlan p;
-    p.on = false; p.grid_body = p.grid_tail = 0; p.tiles_body = 0;
-    if (!BRIEF_TAIL_PLAN || d.precision != BRIEF_PREC_F32 || d.layers - 2 < 1) return p;
+    memset(&p, 0, sizeof(p));
+    if (!BRIEF_TAIL_PLAN || g_tail_mode == 0 || d.precision != BRIEF_PREC_F32 || d.layers - 2 < 1) return p;
     const int nt = brief_nt(d);
-    if (!(brief_use_wide(d) || (BRIEF_TAIL_LEAN && brief_use_lean(d, true) && nt >= 9))) return p;
+    if (nt < 8) return p;
     const int64_t tiles = (n + 31) / 32;
     const int G = fused_grid(d, n, true);
     const int64_t full = tiles / G * G, rem = tiles - full;
-    if (full == 0 || rem == 0 || rem * 4 > 3 * (int64_t)G) return p;      // (a last round that is three quarters full has nothing to give)
+    if (full == 0 || rem == 0) return p;
+    // (9 .. 16 tiles: k_lean with two workgroups per CU, k_wgrad in ONE round.  Measured, 100 000 samples, interleaved with the plan off on one box: 4x320 1.615 -> 1.587 ms,
+    //  4x384 2.177 -> 2.143, 4x448 2.946 -> 2.859, 4x512 3.900 -> 3.794 (+1.8 / 1.6 / 3.0 / 2.8 %).  The headline's k_fused<8> gains 0.3 .. 0.7 % — a solo tail tile takes 70 us
+    //  where the single launch's ragged end costs 41 — and stays one launch; above 16 tiles k_wgrad runs several rounds per XCD and the uneven form loses to the even one
+    //  (4x1024 14.55 -> 14.97 ms, 4x1494 32.8 -> 34.7 against the extra-split form's 32.6).)
+    if (g_tail_mode == 2 && nt >= 9 && nt <= 16 && rem * 4 <= 3 * (int64_t)kCUs) {
+        const int hidden = d.layers - 2, nq = wgrad_nq(nt), qt = (nt + nq - 1) / nq;
+        const int64_t chunks = brief_npad_d(d, n) / 32, B = (int64_t)hidden * nq * nq;
+        const int ns = wgrad_split_rule(d, chunks, 1);
+        // Workgroup i of a launch goes to XCD i mod 8, each XCD has CUs / 8 CUs and a k_wgrad workgroup needs a CU of its own: the normal splits' workgroups + the tail's, and
+        // the normal + the short splits' workgroups, must fit every XCD's CUs, or one workgroup waits a whole round (measured: 201 + 53 on 256 CUs put 26 + 7 on XCD 0 —
+        // k_wgrad 301 -> 400 + 492 us).  Only nets whose k_wgrad is ONE round are planned this way (8 .. 16 tiles).
+        const int per_xcd = kCUs / 8, tail_x = (int)((rem + 7) / 8);
+        int n_norm = 0;
+        if ((int64_t)ns * B <= kCUs)
+            for (int c = ns - 1; c >= 1; --c) {
+                const int a_ = (int)((c * B + 7) / 8), s_ = (int)(((ns - c) * B + 7) / 8);
+                if (a_ + tail_x <= per_xcd && a_ + s_ <= per_xcd && (ns - c) * B >= rem) { n_norm = c; break; }
+            }
+        const int n_short = ns - n_norm;
+        const double r = g_tail_r ? 0.01 * g_tail_r : BRIEF_TAIL_R;
+        const double rho = r * 2.0 * hidden * nt * nt / (double)(qt * qt);
+        const double k_norm = ((double)chunks + n_short * rho) / ns, k_short = k_norm - rho;
+        if (n_norm > 0 && k_short >= 4.0 && rho < 0.8 * k_norm) {
+            p.kfix_n = (int64_t)(k_norm * 65536.0); p.kfix_s = (int64_t)(k_short * 65536.0);
+            const int64_t b_norm = ((int64_t)(ns - n_short) * p.kfix_n) >> 16;      // first chunk of the short splits
+            if (b_norm <= full && b_norm > 0) {                                      // (the normal splits stay inside the body's chunks)
+                p.mode = 2; p.on = true; p.grid_body = G; p.grid_tail = (int)rem; p.tiles_body = full; p.ns = ns; p.n_norm = ns - n_short;
+                return p;
+            }
+        }
+    }
+    // mode 1: the extra-split form, k_wide with many short k_wgrad workgroups
+    if (!(brief_use_wide(d) || (BRIEF_TAIL_LEAN && brief_use_lean(d, true) && nt >= 9))) return p;
+    if (rem * 4 > 3 * (int64_t)G) return p;      // (a last round that is three quarters full has nothing to give)
     if (wgrad_split_rule(d, full, BRIEF_TAIL_MIN_ROUNDS) < BRIEF_TAIL_MIN_SPLITS) return p;
-    p.on = true; p.grid_body = G; p.grid_tail = (int)rem; p.tiles_body = full;
+    p.mode = 1; p.on = true; p.grid_body = G; p.grid_tail = (int)rem; p.tiles_body = full;
     return p;
 }
 // K splits of k_wgrad over `nchunks` 32-sample chunks.  min_rounds > 1 (the tail plan): at least that many rounds of quadrant workgroups
@@ -333,8 +385,8 @@ static int wgrad_splits(const brief_siren_desc &d, int64_t n)
 {
     if (d.layers - 2 <= 0) return 0;
     const TailPlan tp = fused_tail_plan(d, n);
-    if (tp.on) return wgrad_split_rule(d, tp.tiles_body, BRIEF_TAIL_MIN_ROUNDS) + 1;
-    return wgrad_split_rule(d, brief_npad_d(d, n) / 32, 1);
+    if (tp.mode == 1) return wgrad_split_rule(d, tp.tiles_body, BRIEF_TAIL_MIN_ROUNDS) + 1;
+    return wgrad_split_rule(d, brief_npad_d(d, n) / 32, 1);      // (mode 2: the uneven splits are the same count)
 }
 
 // narrow nets (F <= 64, at most 7 hidden layers) train through k_small: no stash, no k_wgrad.
@@ -905,7 +957,9 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
     }
     const bool small = use_small(*d);
     const FusedPlan fp = fused_plan(*d, batch->n, true);
-    const TailPlan tp = small ? TailPlan{false, 0, 0, 0} : fused_tail_plan(*d, batch->n);      // wide fp32 nets: the last round's tiles on a side stream
+    TailPlan tp;      // fp32 nets of 8 tiles and more: the last round's tiles as a launch of their own (fused_tail_plan)
+    memset(&tp, 0, sizeof(tp));
+    if (!small) tp = fused_tail_plan(*d, batch->n);
     const int grid1 = small ? small_grid(*d, batch->n) : (tp.on ? tp.grid_body + tp.grid_tail : fp.grid);      // (= workgroup records)
     const int nsplit = small ? (d->layers > 2 ? grid1 : 0) : wgrad_splits(*d, batch->n);
     const float inv_count = (float)(1.0 / ((double)batch->n * d->cout));
@@ -981,12 +1035,14 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
             ds->aux2_init = true;
         }
         side = ds->aux2;
-        fa.n_begin = 0; fa.n_end = tp.tiles_body * 32; fa.rec_base = 0;
+        fa.n_begin = 0; fa.n_end = tp.tiles_body * 32; fa.rec_base = 0;      // (k_lean, k_wide)
+        fa.pers_wgs = tp.grid_body; fa.pers_tiles = tp.tiles_body;           // (k_fused<8>: persistent workgroups over the body's tiles)
         if (int rc = launch_fused<true>(fa, tp.grid_body, st, pe0, nullptr)) return rc;
         HIP_TRY(hipEventRecord(ds->aux2_fork, st));
         HIP_TRY(hipStreamWaitEvent(side, ds->aux2_fork, 0));
         // the tail stays on the caller's stream, right behind the body (its workgroups are placed first); the body's k_wgrad arrives through the event a moment later
         fa.n_begin = tp.tiles_body * 32; fa.n_end = 0; fa.rec_base = tp.grid_body;
+        fa.pers_wgs = 0;                                                     // (k_fused<8>: one tile per workgroup, from pers_tiles on)
         if (int rc = launch_fused<true>(fa, tp.grid_tail, st, nullptr, pe1)) return rc;      // (the profile pair: body start .. tail end)
     }
     if (prof) ++g_prof_n;
@@ -996,14 +1052,24 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
         memset(&wa, 0, sizeof(wa));
         wa.d = *d; wa.Z = fa.Z; wa.D = fa.D; wa.npad = fa.npad; wa.nsplit = nsplit; wa.slabs = ws + wl.slabs;
         wa.stamps = ws + wl.rec + rec_region_floats(*d) - 256 * 8 * 8;   // tail of the record region (diagnostics)
-        // K range and slabs of a launch: every chunk into nsplit slabs, or (tail plan) the body's chunks into nsplit - 1 and the tail's into the last one
-        const int nsA = tp.on ? nsplit - 1 : nsplit;
-        wa.kb_lo = 0; wa.kb_hi = tp.on ? tp.tiles_body : fa.npad / 32; wa.split_lo = 0; wa.nsplit_here = nsA;
         const int per_split = (d->layers - 2) * wgrad_nq(nt) * wgrad_nq(nt);
-        for (int part = 0; part < (tp.on ? 2 : 1); ++part) {
-            if (part) { wa.kb_lo = tp.tiles_body; wa.kb_hi = fa.npad / 32; wa.split_lo = nsA; wa.nsplit_here = 1; }
-            // (tail plan: the body's chunks on the side stream, the tail's — behind the tail launch — on the caller's)
-            if (int rc = launch_wgrad(*d, wa, wa.nsplit_here * per_split, part || !tp.on ? st : side)) return rc;
+        if (tp.mode == 2) {
+            // uneven splits: the normal ones on the side stream behind the body, the short ones (which end with the tail's chunks) on the caller's behind the tail
+            wa.uneven = 1; wa.n_norm = tp.n_norm; wa.kfix_n = tp.kfix_n; wa.kfix_s = tp.kfix_s;
+            wa.kb_lo = 0; wa.kb_hi = fa.npad / 32;
+            wa.split_lo = 0; wa.nsplit_here = tp.n_norm;
+            if (int rc = launch_wgrad(*d, wa, wa.nsplit_here * per_split, side)) return rc;
+            wa.split_lo = tp.n_norm; wa.nsplit_here = nsplit - tp.n_norm;
+            if (int rc = launch_wgrad(*d, wa, wa.nsplit_here * per_split, st)) return rc;
+        } else {
+            // K range and slabs of a launch: every chunk into nsplit slabs, or (extra-split tail plan) the body's chunks into nsplit - 1 and the tail's into the last one
+            const int nsA = tp.on ? nsplit - 1 : nsplit;
+            wa.kb_lo = 0; wa.kb_hi = tp.on ? tp.tiles_body : fa.npad / 32; wa.split_lo = 0; wa.nsplit_here = nsA;
+            for (int part = 0; part < (tp.on ? 2 : 1); ++part) {
+                if (part) { wa.kb_lo = tp.tiles_body; wa.kb_hi = fa.npad / 32; wa.split_lo = nsA; wa.nsplit_here = 1; }
+                // (the body's chunks on the side stream, the tail's — behind the tail launch — on the caller's)
+                if (int rc = launch_wgrad(*d, wa, wa.nsplit_here * per_split, part || !tp.on ? st : side)) return rc;
+            }
         }
     }
     if (tp.on) {

@@ -63,7 +63,11 @@ def test_forward_wide_vs_oracle(L, F, cin, cout, n):
 
 @pytest.mark.parametrize("L,F,cin,cout,n,oa", [(5, 527, 3, 1, 800, False), (5, 640, 3, 1, 500, False), (5, 1000, 3, 1, 300, False),
                                                 (3, 1024, 2, 3, 300, False), (4, 576, 3, 1, 333, True), (3, 800, 3, 1, 33, False),
-                                                (4, 900, 3, 2, 257, False), (2, 700, 3, 1, 129, False), (3, 672, 3, 1, 8300, False)])
+                                                (4, 900, 3, 2, 257, False), (2, 700, 3, 1, 129, False), (3, 672, 3, 1, 8300, False),
+                                                # 9 .. 16 tiles with more tiles than the 512 resident workgroups and a ragged last round: the UNEVEN tail plan
+                                                # (brief_hip.hip fused_tail_plan, mode 2: body / tail launches of k_lean, k_wgrad's normal splits on the side stream,
+                                                # its short splits — which end with the tail's chunks — behind the tail): 625 = 512 + 113 tiles, 563 = 512 + 51
+                                                (5, 384, 3, 1, 20000, False), (4, 512, 2, 2, 18000, False), (3, 300, 3, 1, 17000, True)])
 def test_train_step_wide_vs_oracle(L, F, cin, cout, n, oa):
     m, d, p = make_net(L, F, 20.0, cin, cout, oa, seed=L * 10 + F)
     rng = np.random.default_rng(F + n)
