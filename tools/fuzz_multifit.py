@@ -30,7 +30,7 @@ for gi in range(groups):
         prec = 'bf16' if (F >= 96 and rng.random() < 0.3) else 'fp32'
         dims = tuple(int(v) for v in rng.choice([8, 12, 16, 20, 24], size=3))
         sampler = str(rng.choice(['full', 'randompoint']))
-        n = int(rng.choice([100, 1000, 3333, 5000, 9000])) if sampler == 'randompoint' else 0
+        n = int(rng.choice([100, 1000, 3333, 5000, 9000, 20000])) if sampler == 'randompoint' else 0
         specs.append((L, F, prec, dims, sampler, n, str(rng.choice(['Adamax', 'Adam']))))
     steps = int(rng.integers(3, 25))
     alone = [make(s, 10 * gi + i) for i, s in enumerate(specs)]
