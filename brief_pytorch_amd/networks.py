@@ -260,6 +260,8 @@ class SIREN:
         self._require_gpu()
         if self.packed is None:
             n = _lib.lib().brief_packed_count(C.byref(self.desc))
+            if n < 0:      # (a shape the library refuses, e.g. precision = 'bf16' above 512 features: its message, not a torch allocation error)
+                raise _lib.BriefError(_lib.lib().brief_last_error().decode())
             self.packed = torch.empty(n, dtype=torch.float32, device=self.params.device)
             self._stale = True
         if self.params._version != self._seen_version:      # torch changed the parameters in place (e.g. optimizer.step())

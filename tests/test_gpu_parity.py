@@ -478,6 +478,11 @@ def test_errors_are_loud():
     m, _, _ = make_net(3, 16, 20.0)
     with pytest.raises(_lib.BriefError):
         m.train_step(10, torch.zeros(10, 1, device=DEV), coords=None, grid=((4, 4), -1.0, 1.0))   # ndim != cin
+    # a shape the library refuses surfaces as ITS message from the module, not as a torch allocation error on a count of -1
+    from brief_pytorch_amd.networks import SIREN
+    wide16 = SIREN(features=1100, layers=4, w0=20, precision="bf16").to(DEV)       # the bf16 path stops at 512 features
+    with pytest.raises(_lib.BriefError, match="512"):
+        wide16.sync_packed()
 
 
 def test_deblock_vs_oracle_and_golden(golden):

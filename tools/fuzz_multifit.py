@@ -27,7 +27,7 @@ for gi in range(groups):
     for _ in range(k):
         F = int(rng.choice([5, 22, 33, 56, 64, 96, 130, 200, 256, 340, 527, 1100])) if k < 8 else int(rng.choice([5, 22, 22, 30, 33, 56, 64, 96]))
         L = int(rng.integers(3, 8))
-        prec = 'bf16' if (F >= 96 and rng.random() < 0.3) else 'fp32'
+        prec = 'bf16' if (96 <= F <= 512 and rng.random() < 0.3) else 'fp32'      # (the bf16 path stops at 512 features)
         dims = tuple(int(v) for v in rng.choice([8, 12, 16, 20, 24], size=3))
         sampler = str(rng.choice(['full', 'randompoint']))
         n = int(rng.choice([100, 1000, 3333, 5000, 9000, 20000])) if sampler == 'randompoint' else 0
