@@ -254,6 +254,7 @@ static FusedPlan fused_plan(const brief_siren_desc &d, int64_t n, bool train)
 #endif
 #ifndef BRIEF_TAIL_R
 #define BRIEF_TAIL_R 1.15      // measured (tools/width_sweep.py over r = 0.5 .. 2.0, diagnostics build): 1.1 .. 1.2 is the flat optimum at 320, 384, 448 and 512 features
+#define BRIEF_TAIL_R1 1.05     // ... above 16 tiles (one k_lean workgroup per CU: the body's tiles run solo too): 0.9 / 1.05 / 1.25 -> 4x768 8.215 / 8.179 / 8.220 ms
 #endif
 #ifndef BRIEF_TAIL_MIN_SPLITS
 #define BRIEF_TAIL_MIN_SPLITS 6
@@ -286,6 +287,7 @@ static FusedPlan fused_plan(const brief_siren_desc &d, int64_t n, bool train)
 struct TailPlan { int mode /* 0 off, 1 extra split, 2 uneven splits */; bool on; int grid_body, grid_tail; int64_t tiles_body; int ns, n_norm; int64_t kfix_n, kfix_s; };
 static int wgrad_split_rule(const brief_siren_desc &d, int64_t nchunks, int min_rounds);
 static const int g_tail_mode = env_int("BRIEF_TAIL_MODE", BRIEF_TAIL_MODE_DEFAULT, 0, 2);      // diagnostics: 0 no tail plan, 1 the extra-split form only, 2 uneven splits where eligible
+static const int g_tail_ntmax = env_int("BRIEF_TAIL_NTMAX", 32, 9, 32);                        // diagnostics: the uneven form up to this many tiles
 static const int g_tail_r = env_int("BRIEF_TAIL_R", 0, 0, 1000);                               // diagnostics: r in percent (0: the class's own)
 static TailPlan fused_tail_plan(const brief_siren_desc &d, int64_t n)
 {
@@ -298,14 +300,18 @@ static TailPlan fused_tail_plan(const brief_siren_desc &d, int64_t n)
     const int G = fused_grid(d, n, true);
     const int64_t full = tiles / G * G, rem = tiles - full;
     if (full == 0 || rem == 0) return p;
-    // (9 .. 16 tiles: k_lean with two workgroups per CU, k_wgrad in ONE round.  Measured, 100 000 samples, interleaved with the plan off on one box: 4x320 1.615 -> 1.587 ms,
+    // (9 .. 32 tiles: k_lean, k_wgrad in ONE round.  9 .. 16 tiles, two workgroups per CU:  Measured, 100 000 samples, interleaved with the plan off on one box: 4x320 1.615 -> 1.587 ms,
     //  4x384 2.177 -> 2.143, 4x448 2.946 -> 2.859, 4x512 3.900 -> 3.794 (+1.8 / 1.6 / 3.0 / 2.8 %).  The headline's k_fused<8> gains 0.3 .. 0.7 % — a solo tail tile takes 70 us
-    //  where the single launch's ragged end costs 41 — and stays one launch; above 16 tiles k_wgrad runs several rounds per XCD and the uneven form loses to the even one
-    //  (4x1024 14.55 -> 14.97 ms, 4x1494 32.8 -> 34.7 against the extra-split form's 32.6).)
-    if (g_tail_mode == 2 && nt >= 9 && nt <= 16 && rem * 4 <= 3 * (int64_t)kCUs) {
+    //  where the single launch's ragged end costs 41 — and stays one launch; where k_wgrad runs several rounds per XCD the uneven form loses to the even one
+    //  (4x1024 with 14 + 2 splits 14.55 -> 14.97 ms, 4x1494 32.8 -> 34.7 against the extra-split form's 32.6).)
+    if (g_tail_mode == 2 && nt >= 9 && nt <= g_tail_ntmax && rem * 4 <= 3 * (int64_t)kCUs) {
         const int hidden = d.layers - 2, nq = wgrad_nq(nt), qt = (nt + nq - 1) / nq;
         const int64_t chunks = brief_npad_d(d, n) / 32, B = (int64_t)hidden * nq * nq;
-        const int ns = wgrad_split_rule(d, chunks, 1);
+        int ns = wgrad_split_rule(d, chunks, 1);
+        // 17 .. 32 tiles: the split rule's three rounds of k_wgrad (28 x 27 or 16 x 48 workgroups) are re-cut into ONE round (9 x 27 = 243, 5 x 48 = 240), where the uneven
+        // form applies.  Measured against the three even rounds (tools/width_sweep.py, two interleaved rounds): 4x527 4.651 -> 4.524 ms, 4x640 6.235 -> 6.063, 4x768 8.464 -> 8.190
+        // (+2.8 .. 3.3 %); 4x896 11.44 -> 11.39, 4x1024 14.60 -> 14.49 (+0.4 .. 0.8 %: five splits leave 16 CUs idle, which the even 16-split cut does not)
+        if ((int64_t)ns * B > kCUs) ns = (int)(kCUs / B);
         // Workgroup i of a launch goes to XCD i mod 8, each XCD has CUs / 8 CUs and a k_wgrad workgroup needs a CU of its own: the normal splits' workgroups + the tail's, and
         // the normal + the short splits' workgroups, must fit every XCD's CUs, or one workgroup waits a whole round (measured: 201 + 53 on 256 CUs put 26 + 7 on XCD 0 —
         // k_wgrad 301 -> 400 + 492 us).  Only nets whose k_wgrad is ONE round are planned this way (8 .. 16 tiles).
@@ -317,7 +323,7 @@ static TailPlan fused_tail_plan(const brief_siren_desc &d, int64_t n)
                 if (a_ + tail_x <= per_xcd && a_ + s_ <= per_xcd && (ns - c) * B >= rem) { n_norm = c; break; }
             }
         const int n_short = ns - n_norm;
-        const double r = g_tail_r ? 0.01 * g_tail_r : BRIEF_TAIL_R;
+        const double r = g_tail_r ? 0.01 * g_tail_r : (nt <= 16 ? BRIEF_TAIL_R : BRIEF_TAIL_R1);
         const double rho = r * 2.0 * hidden * nt * nt / (double)(qt * qt);
         const double k_norm = ((double)chunks + n_short * rho) / ns, k_short = k_norm - rho;
         if (n_norm > 0 && k_short >= 4.0 && rho < 0.8 * k_norm) {
@@ -386,7 +392,8 @@ static int wgrad_splits(const brief_siren_desc &d, int64_t n)
     if (d.layers - 2 <= 0) return 0;
     const TailPlan tp = fused_tail_plan(d, n);
     if (tp.mode == 1) return wgrad_split_rule(d, tp.tiles_body, BRIEF_TAIL_MIN_ROUNDS) + 1;
-    return wgrad_split_rule(d, brief_npad_d(d, n) / 32, 1);      // (mode 2: the uneven splits are the same count)
+    if (tp.mode == 2) return tp.ns;
+    return wgrad_split_rule(d, brief_npad_d(d, n) / 32, 1);
 }
 
 // narrow nets (F <= 64, at most 7 hidden layers) train through k_small: no stash, no k_wgrad.

@@ -67,7 +67,9 @@ def test_forward_wide_vs_oracle(L, F, cin, cout, n):
                                                 # 9 .. 16 tiles with more tiles than the 512 resident workgroups and a ragged last round: the UNEVEN tail plan
                                                 # (brief_hip.hip fused_tail_plan, mode 2: body / tail launches of k_lean, k_wgrad's normal splits on the side stream,
                                                 # its short splits — which end with the tail's chunks — behind the tail): 625 = 512 + 113 tiles, 563 = 512 + 51
-                                                (5, 384, 3, 1, 20000, False), (4, 512, 2, 2, 18000, False), (3, 300, 3, 1, 17000, True)])
+                                                (5, 384, 3, 1, 20000, False), (4, 512, 2, 2, 18000, False), (3, 300, 3, 1, 17000, True),
+                                                # ... and 17 .. 32 tiles (one workgroup per CU, k_wgrad re-cut into one round): 282 = 256 + 26 tiles, 297 = 256 + 41
+                                                (5, 527, 3, 1, 9000, False), (4, 1024, 3, 1, 9500, False)])
 def test_train_step_wide_vs_oracle(L, F, cin, cout, n, oa):
     m, d, p = make_net(L, F, 20.0, cin, cout, oa, seed=L * 10 + F)
     rng = np.random.default_rng(F + n)
