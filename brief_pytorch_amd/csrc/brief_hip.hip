@@ -39,6 +39,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
+#include <mutex>
 #include "brief_layout.h"
 #include "brief_math.h"
 
@@ -116,8 +117,14 @@ static int current_device()
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
     return dev;
 }
+// Host threads: the per-device state (attributes set, stream / event pools) is created lazily, and a train step that forks onto a side stream records and waits on the
+// device's ONE pair of fork / join events — two threads enqueueing on one device at the same time would wait on each other's records.  Everything that touches that state
+// runs under this (recursive: brief_multi_fit -> fit steps) lock; the calls only ENQUEUE, so it is held for microseconds.  Different devices do not share state but share
+// the lock (one process per GPU is the deployment: SURVEY 8e).
+static std::recursive_mutex g_state_mu;
 static DevState *dev_state()
 {
+    std::lock_guard<std::recursive_mutex> lk(g_state_mu);
     static DevState *tab[kMaxDevices] = {};
     const int dev = current_device();
     if (!tab[dev]) tab[dev] = (DevState *)calloc(1, sizeof(DevState));
@@ -126,6 +133,7 @@ static DevState *dev_state()
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel, size)
 static int dev_attr_once(const void *fn, int bytes)
 {
+    std::lock_guard<std::recursive_mutex> lk(g_state_mu);
     DevState *ds = dev_state();
     if (!ds) return fail(BRIEF_ERR_INVALID, "out of host memory");
     for (int i = 0; i < ds->nattr; ++i)
@@ -847,6 +855,7 @@ static int train_step_impl(const brief_siren_desc *d, const float *packed, const
                            float *grads, float *loss_out, float *yhat_out,
                            void *workspace, int64_t workspace_bytes, void *stream, const UpdatePayload *upd, SmallStepPlan *plan_only = nullptr)
 {
+    std::lock_guard<std::recursive_mutex> state_lock(g_state_mu);      // (the side-stream plans below: see g_state_mu)
     if (int rc = check_desc(d)) return rc;
     if (int rc = check_batch(d, grid, batch, true)) return rc;
     if (!packed || !grads || !loss_out || !workspace) return fail(BRIEF_ERR_INVALID, "null buffer");
@@ -1248,6 +1257,7 @@ int brief_multi_fit(const brief_fit_job *jobs, int32_t njobs, int64_t steps, voi
     for (int j = 0; j < njobs; ++j)
         if (int rc = fit_job_check(&jobs[j])) return rc;
     if (njobs == 1) return brief_siren_fit(jobs, steps, stream);
+    std::lock_guard<std::recursive_mutex> state_lock(g_state_mu);
     DevState *ds = dev_state();      // the stream / event pool of the CURRENT device (created on first use there)
     if (!ds) return fail(BRIEF_ERR_INVALID, "out of host memory");
     if (!ds->pool_init) {
@@ -1332,6 +1342,7 @@ int brief_optim_step(int kind, float *params, const float *grads, float *state1,
 
 int brief_profile_enable(int on)
 {
+    std::lock_guard<std::recursive_mutex> state_lock(g_state_mu);
     DevState *ds = dev_state();
     if (!ds) return fail(BRIEF_ERR_INVALID, "out of host memory");
     if (on && !ds->prof_init) {

@@ -192,3 +192,47 @@ def test_side_stream_plans_survive_graph_capture(F, n, prec):
     torch.cuda.synchronize()
     assert float(a.grads.abs().max()) > 0 and torch.equal(a.grads, b.grads)
 
+
+
+def test_two_host_threads_fit_on_one_device_with_the_side_stream_plans():
+    """two host threads enqueue fits on one device at the same time, each on a torch stream of its own; both nets take a side-stream plan (the extra-split form at 1 100
+    features, the uneven form at 512), whose fork / join events and side stream exist once per device — the library serialises the ENQUEUE (g_state_mu): results equal the
+    same fits run one after the other, bit for bit"""
+    import threading
+    dims = (48, 48, 48)
+    torch.manual_seed(3)
+    tv = torch.rand(48 ** 3, 1, device=DEV) * 100
+    specs = [(1100, 9000, 11), (512, 18000, 12)]
+
+    def make(F, n, seed):
+        torch.manual_seed(seed)
+        m = SIREN(features=F, layers=4, w0=20).to(DEV)
+        return Fitter(m, tv, dims, sampler="randompoint", sample_size=n, seed=seed)
+
+    solo = [make(*s) for s in specs]
+    for f in solo:
+        f.run(12)
+    torch.cuda.synchronize()
+    both = [make(*s) for s in specs]
+    errs = []
+
+    def work(f):
+        try:
+            st = torch.cuda.Stream()
+            st.wait_stream(torch.cuda.default_stream())
+            with torch.cuda.stream(st):
+                for _ in range(12):
+                    f.run(1)
+            st.synchronize()
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(f,)) for f in both]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errs, errs
+    for a, b in zip(solo, both):
+        assert torch.equal(a.m.params, b.m.params) and torch.equal(a.m.packed, b.m.packed)
