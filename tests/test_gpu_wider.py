@@ -162,7 +162,7 @@ def test_cli_default_yaml_on_a_1024_cube_solves_to_1494_features_and_runs(tmp_pa
     assert psnr > 25.0                                                                   # 60 steps only: a floor, not a quality claim
 
 
-@pytest.mark.parametrize("F,n,prec", [(1100, 9000, "fp32"), (512, 100000, "bf16")])
+@pytest.mark.parametrize("F,n,prec", [(1100, 9000, "fp32"), (512, 18000, "fp32"), (768, 9000, "fp32"), (512, 100000, "bf16")])
 def test_side_stream_plans_survive_graph_capture(F, n, prec):
     """the tail plan of the wide fp32 nets and the bf16 overlap plan fork part of a train step onto the library's own side stream and join it
     back by events: captured into a graph on torch's capture stream the fork / join become graph edges — three replays of one
